@@ -1,0 +1,240 @@
+/*
+ * reid_hip.h -- C-ABI of libreid_hip.so, the MI355X (gfx950) kernels of the
+ * PRCV2025REID hot path.
+ *
+ * The reference (LingmaFuture/PRCV2025REID) is pure Python on PyTorch and has no
+ * FFI of its own; every entry point below therefore cites the
+ * reference *Python* code whose arithmetic it replaces.  The boundary a user of
+ * the reference sees is the Python surface in prcv2025reid_amd/model.py, which
+ * calls these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative reid_status otherwise;
+ *     reid_last_error() returns a thread-local message for the last failure;
+ *   - all pointers are DEVICE pointers unless named host_*; nothing is allocated
+ *     or synchronised inside a call; `stream` is a hipStream_t passed as void*;
+ *   - matrices are row-major with explicit leading dimensions in ELEMENTS;
+ *   - bf16 = upper 16 bits of IEEE fp32 (round-to-nearest-even on conversion).
+ */
+#ifndef REID_HIP_H
+#define REID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    REID_OK = 0,
+    REID_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size */
+    REID_ERR_LAUNCH = -2,   /* hipLaunch / hipGetLastError failed          */
+    REID_ERR_DEVICE = -3    /* not a gfx950 device                         */
+} reid_status;
+
+typedef enum { REID_BF16 = 0, REID_F32 = 1 } reid_dtype;
+
+typedef enum {
+    REID_ACT_NONE = 0,
+    REID_ACT_GELU_ERF = 1,    /* nn.GELU() exact, models/mer_lora.py:257             */
+    REID_ACT_QUICK_GELU = 2,  /* HF CLIP text MLP x*sigmoid(1.702x)                   */
+    REID_ACT_RELU = 3,        /* models/model.py:42                                   */
+    REID_ACT_DGELU_ERF = 4,   /* out = acc * gelu'(aux)        (backward of 1)        */
+    REID_ACT_DQUICK_GELU = 5, /* out = acc * quick_gelu'(aux)  (backward of 2)        */
+    REID_ACT_DRELU = 6        /* out = acc * (aux > 0)                                */
+} reid_act;
+
+const char* reid_last_error(void);
+int reid_version(void);
+/* Checks that device `dev` is gfx950 (MI355X).  */
+int reid_check_device(int dev);
+
+/* ------------------------------------------------------------------------------------------
+ * MER GEMM:  C = epilogue( A . B^T  +  A2 . B2^T + bias )      bf16 MFMA, fp32 accumulate
+ *
+ * Replaces MERLinear.forward (models/mer_lora.py:80-99: shared_linear(x) + lora_B(lora_A(x))*s)
+ * and, with A2 = NULL, every plain nn.Linear on the path (models/clip_backbone.py:284,311;
+ * HF CLIP text q/k/v/out/fc1/fc2) and their dX backward products.
+ *   A  [M, K]  bf16 activations          B  [N, K]  bf16 weight (nn.Linear layout)
+ *   A2 [M, *]  bf16 low-rank activations B2 [N, K2] bf16 (scaled LoRA up-projection)
+ *   The low-rank pair extends the K loop by K2 (multiple of 32) columns.  With
+ *   k2_group_n > 0 output columns [g*k2_group_n, (g+1)*k2_group_n) read A2 columns
+ *   [g*K2, (g+1)*K2)  (fused q|k|v projection: one adapter set per projection).
+ * Epilogue, in order: + bias[n]; + R (residual, r_dtype; row index m, or m % r_period when
+ *   r_period > 0, e.g. the position embedding of models/clip_backbone.py:273); C2 = value
+ *   (pre-activation, optional); activation `act` (for the D* forms `aux` [M, ldaux] bf16 holds
+ *   the saved pre-activation); row-modality mask (mask_r > 0: column c is kept only if
+ *   (c % K_mask_period)/mask_r == img_mod[m / rows_per_img], the LoRA routing of
+ *   mer_lora.py:96 for a batch that mixes modalities); * alpha; store as c_dtype at row
+ *   (m / c_group) * c_group_stride + m % c_group + c_row_off when c_group > 0 (patch rows ->
+ *   token rows behind the CLS slot, models/clip_backbone.py:269-270), else row m.
+ * Requirements: K % 64 == 0 or K % 32 == 0, K2 % 32 == 0, N % 4 == 0, 16-byte aligned rows.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* A; const void* B; const void* A2; const void* B2;
+    const float* bias;
+    const void* R; const void* aux;
+    void* C; void* C2;
+    const int32_t* img_mod;
+    int32_t M, N, K, K2;
+    int32_t lda, ldb, lda2, ldb2, ldr, ldaux, ldc, ldc2;
+    int32_t k2_group_n;
+    int32_t act, c_dtype, c2_dtype, r_dtype;
+    int32_t r_period;
+    int32_t mask_r, mask_period, rows_per_img;
+    int32_t c_group, c_group_stride, c_row_off;
+    float alpha;
+} reid_gemm_args;
+int reid_mer_gemm(const reid_gemm_args* host_args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reduce-over-rows GEMM:  C[P, Q] = beta*C + alpha * X[M, P]^T . Y[M, Q]   (fp32 out)
+ * Weight-gradient products of the backward pass: dB = dY^T T and dA = U^T X for LoRA
+ * (autograd of models/mer_lora.py:48), dW = dY^T X for unfrozen linears.
+ * X, Y bf16; partial sums over row slabs are combined with fp32 atomics (C must hold
+ * beta*C on entry; this call zero-fills C itself when beta == 0).
+ * ------------------------------------------------------------------------------------------ */
+int reid_gemm_tn(const void* X, const void* Y, float* C, int32_t M, int32_t P, int32_t Q,
+                 int32_t ldx, int32_t ldy, int32_t ldc, float alpha, float beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps 1e-5; models/clip_backbone.py:35-36,73-75,82,210,280).
+ *   fwd: y = (x-mean)*rstd*gamma+beta; x f32 [rows, ld]; y bf16 and/or f32; saves mean/rstd.
+ *        row_index != NULL gathers x rows (CLS rows, clip_backbone.py:281: LN is per-row, so
+ *        only the rows that are used get normalised).
+ *   bwd: dx = dres + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  dy bf16 or f32.
+ *        writes dx f32 and optional bf16 copy; dgamma/dbeta (f32 [cols], atomically
+ *        accumulated) only when non-NULL.  row_index != NULL scatters into rows of dx.
+ * ------------------------------------------------------------------------------------------ */
+int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
+                       const float* beta, void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd,
+                       int32_t rows, int32_t cols, float eps, void* stream);
+int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
+                       const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
+                       const float* dres, float* dx, void* dx_bf16, int32_t lddx,
+                       float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch extraction (im2col of the k=s=16 conv, models/patch_embeds.py:45-76):
+ *   images f32 [n_img, 3, H, W] -> patches bf16 [n_img*(H/16)*(W/16), cin*256]; cin == 1 first
+ *   averages the three channels (patch_embeds.py:63-65).  The conv itself is reid_mer_gemm.
+ * cls rows: x[img*tokens + 0] = cls + pos[0]   (models/clip_backbone.py:269-273)
+ * ------------------------------------------------------------------------------------------ */
+int reid_patch_im2col(const float* images, void* patches, int32_t n_img, int32_t H, int32_t W,
+                      int32_t patch, int32_t cin, void* stream);
+int reid_cls_rows(const float* cls, const float* pos0, float* x, int32_t ldx, int32_t n_img,
+                  int32_t tokens, int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention, head_dim 64, sequences of S <= 224 tokens held on chip
+ * (MERMultiheadAttention SDPA call, models/mer_lora.py:166-190, scale 1/8; HF CLIP text
+ *  attention with causal + key-padding mask; nn.MultiheadAttention of FeatureFusion,
+ *  models/model.py:152-155).
+ *   qkv bf16 [n_seq*S, ld] with q at column 0, k at column d, v at column 2d (d = heads*64).
+ *   key_mask uint8 [n_seq, S] (1 = attend) or NULL; causal != 0 adds key <= query.
+ *   out bf16 [n_seq*S, ldo]; lse f32 [n_seq, heads, S] (natural-log-sum-exp of scaled scores).
+ *   bwd writes dqkv bf16 in the qkv layout.
+ * ------------------------------------------------------------------------------------------ */
+int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mask, void* out, int32_t ldo, float* lse,
+                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream);
+int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mask, const void* out, const void* dout,
+                  int32_t ldo, const float* lse, void* dqkv, int32_t lddqkv, float* delta_ws,
+                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise helpers.
+ * ------------------------------------------------------------------------------------------ */
+int reid_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int reid_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */
+int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd,
+                         int32_t rows, int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BN-neck (BNNeck.forward, models/model.py:208-224): BatchNorm1d(D) -> 8*L2-normalise.
+ *   training != 0: batch statistics over `rows` (biased variance), running stats updated with
+ *   momentum 0.1 / unbiased variance; else running statistics.  The classifier GEMM that
+ *   follows is reid_mer_gemm on the bf16 copy.
+ *   With ext_sum/ext_sqsum/ext_count non-NULL the statistics are taken from those buffers
+ *   (data-parallel SyncBN: the caller all-reduces them between the two phases).
+ *   fwd outputs: y f32 [rows, D] (norm 8 per row), y_bf16 optional, saved xhat-free state:
+ *   mean[D], invstd[D], rnorm[rows].
+ * ------------------------------------------------------------------------------------------ */
+int reid_bnneck_stats(const float* x, int32_t ldx, int32_t rows, int32_t D, float* sum, float* sqsum, void* stream);
+int reid_bnneck_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, const float* sum, const float* sqsum, float count, int32_t training,
+                    float* y, void* y_bf16, int32_t ldy, float* mean, float* invstd, float* rnorm,
+                    int32_t rows, int32_t D, float eps, float momentum, float scale, void* stream);
+/* bwd phase 1: per-row L2-normalise backward -> dz (grad wrt BN output), and column sums
+ *   sum_dz[D], sum_dz_xhat[D] (all-reduced by the caller under data parallelism);
+ * bwd phase 2: dx = gamma*invstd*(dz - sum_dz/count - xhat*sum_dz_xhat/count); dgamma = sum_dz_xhat; dbeta = sum_dz */
+int reid_bnneck_bwd_p1(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* gamma,
+                       const float* beta, const float* mean, const float* invstd, const float* rnorm,
+                       float* dz, float* sum_dz, float* sum_dz_xhat, int32_t rows, int32_t D, float scale,
+                       void* stream);
+int reid_bnneck_bwd_p2(const float* dz, const float* x, int32_t ldx, const float* gamma, const float* mean,
+                       const float* invstd, const float* sum_dz, const float* sum_dz_xhat, float count,
+                       int32_t training, float* dx, int32_t lddx, int32_t rows, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cross entropy with label smoothing (nn.CrossEntropyLoss(label_smoothing=0.1), models/model.py:290,
+ * 529-549): mean over rows with valid[r] != 0 and 0 <= label < C.
+ *   loss_sum[0] += sum of row losses, loss_sum[1] += number of rows used (both f32, zeroed by caller);
+ *   dlogits = (softmax - smoothed one-hot) * grad_scale for used rows, 0 otherwise (grad_scale =
+ *   ce_weight / global_count, read from device memory so no host sync is needed).
+ * ------------------------------------------------------------------------------------------ */
+int reid_ce_ls_fwd(const float* logits, int32_t ld, const int64_t* labels, const uint8_t* valid, int32_t rows,
+                   int32_t C, float smoothing, float* row_loss, float* loss_sum, void* stream);
+int reid_ce_ls_bwd(const float* logits, int32_t ld, const int64_t* labels, const uint8_t* valid, int32_t rows,
+                   int32_t C, float smoothing, const float* grad_scale, float* dlogits, int32_t lddl, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SDM loss (sdm_loss_stable, models/sdm_loss.py:13-149) between one modality and vis:
+ *   q [N, D], g [Mg, D] f32; q_valid/g_valid uint8 (rows that take part, models/model.py:570,595);
+ *   positives y[i,j] = (q_label[i] == g_label[j]) (models/model.py:605); tau clamped to [0.15, 0.5];
+ *   S = qn.gn^T/tau clamped to +-20; result[0] = 0.5*(mean_rows CE(q->g) + mean_cols CE(g->q)) over
+ *   rows/cols with >= 1 positive; result[1] = 1 if the pair contributes (any positive), else 0.
+ *   No N x Mg matrix is written to HBM in fwd; ws holds 2*(N+Mg)+2 floats of row/col statistics.
+ *   bwd: dq, dg (+= into f32 [*, D]) for upstream grad `gscale[0]` (device scalar).
+ * ------------------------------------------------------------------------------------------ */
+int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label,
+                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg,
+                 int32_t D, float tau, float* ws, float* result, void* stream);
+int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label,
+                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg,
+                 int32_t D, float tau, const float* ws, const float* gscale, float* dq, int32_t lddq, float* dg,
+                 int32_t lddg, void* stream);
+int64_t reid_sdm_ws_floats(int32_t N, int32_t Mg);
+
+/* ------------------------------------------------------------------------------------------
+ * Retrieval (train.py:499 + :463; tools/eval_mm_protocol.py:50-53,401-423,622-625):
+ *   sim = Q . G^T on L2-normalised rows, per-query top-k in (score desc, index asc) order.
+ *   Q [Nq, D], G [Ng, D] bf16 copies drive a tiled MFMA GEMM with an on-chip candidate filter;
+ *   survivors are re-scored in fp32 from Qf/Gf so the order equals the fp32 oracle's.
+ *   exclude_q/exclude_g (int32 ids, or NULL): entries with equal non-negative id get -1e9
+ *   (same-image mask, eval_mm_protocol.py:421-422).
+ *   out_idx int32 [Nq, k], out_score f32 [Nq, k].  ws: reid_topk_ws_bytes().
+ * ------------------------------------------------------------------------------------------ */
+int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k);
+int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf,
+                     int32_t Nq, int32_t Ng, int32_t D, int32_t k, const int32_t* exclude_q,
+                     const int32_t* exclude_g, void* ws, int32_t* out_idx, float* out_score, void* stream);
+/* Exact fp32 pass for the queries reid_cosine_topk flagged with out_idx[q][0] == -2 (candidate list
+ * overflow, e.g. thousands of near-duplicates); scratch holds Nq*Ng floats; other queries are untouched. */
+int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                           const int32_t* exclude_q, const int32_t* exclude_g, float* scratch, int32_t* out_idx,
+                           float* out_score, void* stream);
+/* fp32 C[M,N] = act(alpha * op(A).op(B) + bias[n]) + beta*C on the vector ALU with arbitrary element strides
+ * (A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]); the small exact GEMMs of the head
+ * (models/model.py:57-77,152-162) and of the SDM loss. */
+int reid_sgemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak,
+               int64_t sbk, int64_t sbn, int32_t ldc, float alpha, float beta, const float* bias, int32_t act,
+               void* stream);
+/* L2-normalise rows (F.normalize, train.py:442): x f32 [rows, D] -> y f32 and/or bf16. */
+int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t D,
+                     float eps, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REID_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libreid_hip.so (include/reid_hip.h).  No CPU fallback exists:
+if the library is missing or a call fails this module raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libreid_hip.so')
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU = range(7)
+
+EXPORTS = [
+    'reid_last_error', 'reid_version', 'reid_check_device', 'reid_mer_gemm', 'reid_gemm_tn',
+    'reid_layernorm_fwd', 'reid_layernorm_bwd', 'reid_patch_im2col', 'reid_cls_rows',
+    'reid_attn_fwd', 'reid_attn_bwd', 'reid_cast_f32_bf16', 'reid_cast_bf16_f32', 'reid_gather_rows_f32',
+    'reid_bnneck_stats', 'reid_bnneck_fwd', 'reid_bnneck_bwd_p1', 'reid_bnneck_bwd_p2',
+    'reid_ce_ls_fwd', 'reid_ce_ls_bwd', 'reid_sdm_fwd', 'reid_sdm_bwd', 'reid_sdm_ws_floats',
+    'reid_topk_ws_bytes', 'reid_cosine_topk', 'reid_cosine_topk_exact', 'reid_l2norm_rows', 'reid_sgemm',
+]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('A2', C.c_void_p), ('B2', C.c_void_p),
+                ('bias', C.c_void_p), ('R', C.c_void_p), ('aux', C.c_void_p), ('C', C.c_void_p), ('C2', C.c_void_p),
+                ('img_mod', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('K2', C.c_int32),
+                ('lda', C.c_int32), ('ldb', C.c_int32), ('lda2', C.c_int32), ('ldb2', C.c_int32),
+                ('ldr', C.c_int32), ('ldaux', C.c_int32), ('ldc', C.c_int32), ('ldc2', C.c_int32),
+                ('k2_group_n', C.c_int32),
+                ('act', C.c_int32), ('c_dtype', C.c_int32), ('c2_dtype', C.c_int32), ('r_dtype', C.c_int32),
+                ('r_period', C.c_int32),
+                ('mask_r', C.c_int32), ('mask_period', C.c_int32), ('rows_per_img', C.c_int32),
+                ('c_group', C.c_int32), ('c_group_stride', C.c_int32), ('c_row_off', C.c_int32),
+                ('alpha', C.c_float)]
+
+
+_lib = None
+
+
+class ReidHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ReidHipError(f'{LIB_PATH} not found: build it with `python -m prcv2025reid_amd.build` '
+                               '(there is no CPU or PyTorch fallback for the hot path)')
+        _lib = C.CDLL(LIB_PATH)
+        _lib.reid_last_error.restype = C.c_char_p
+        missing = [n for n in EXPORTS if not hasattr(_lib, n)]
+        if missing:
+            raise ReidHipError(f'{LIB_PATH} lacks symbols {missing}: stale build, run `python -m prcv2025reid_amd.build --force`')
+        _lib.reid_sdm_ws_floats.restype = C.c_int64
+        _lib.reid_topk_ws_bytes.restype = C.c_int64
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise ReidHipError(f'libreid_hip: rc={rc}: {lib().reid_last_error().decode()}')
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def dt(t) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def _req(t, dtype=None, name='tensor'):
+    if not t.is_cuda:
+        raise ReidHipError(f'{name} must be a CUDA(HIP) tensor')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f'{name}: last dim must be contiguous')
+
+
+def ld(t) -> int:
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]

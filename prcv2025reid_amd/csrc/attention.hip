@@ -1,0 +1,409 @@
+// Multi-head attention for short sequences (S <= 224, head_dim 64) on gfx950.
+//
+// One workgroup = one (sequence, head); the whole K and V of the head live in LDS (<= 56 KB), one
+// wavefront per 32-row tile of the other operand.  All products run on v_mfma_f32_32x32x16_bf16 in
+// the "keys/queries on the lane" orientation of cdna_hip_programming.md (section 3, "An accumulator
+// tile as the next MFMA's operand"): the score tile is computed TRANSPOSED (S^T = K.Q^T) so that a
+// lane owns one query column -- the softmax row reduction is in-register plus one cross-half
+// shuffle, and the exponentiated tile P^T is already the B operand of O^T = V^T.P^T, no LDS round
+// trip.  V is staged row-major like K and consumed through the hardware transpose read
+// ds_read_b64_tr_b16.  The backward pass is two kernels of the same shape (dK/dV with keys on the
+// lane, dQ with queries on the lane), each needing only products that sum over the accumulator's
+// row index; P is recomputed from the saved log-sum-exp.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s4;
+typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 1) & 7); }
+
+// stage rows [0, rows_pad) x 64 bf16 of one head (column offset col0 of a [*, ld] matrix) into a
+// swizzled [rows_pad][64] LDS image; rows >= S are zero.
+__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ base, int ld, int S, int rows_pad, char* lds, int tid,
+                                           int nthreads) {
+    for (int t = tid; t < rows_pad * 8; t += nthreads) {
+        const int row = t >> 3, pch = t & 7;
+        const int c = swz(row, pch);
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (row < S) v = *(const uint4*)(base + (size_t)row * ld + c * 8);
+        *(uint4*)(lds + row * 128 + pch * 16) = v;
+    }
+}
+
+// A operand (32 rows x 16 k) of mfma_32x32x16 from a swizzled row-major image: rows = image rows.
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row0, int kchunk, int lane) {
+    const int row = row0 + (lane & 31);
+    return *(const bf16x8*)(img + row * 128 + (swz(row, kchunk + (lane >> 5)) << 4));
+}
+
+// A operand whose 32 MFMA rows are image COLUMNS col0..col0+31 and whose 16 k are image rows, in the
+// accumulator-as-operand k order: element j of lane half h = image row krow0 + 8(j>>2) + 4h + (j&3).
+__device__ __forceinline__ bf16x8 col_frag(const char* img, int krow0, int col0, int lane) {
+    const int h = lane >> 5, half16 = (lane >> 4) & 1, i = lane & 15;
+    const int q = i >> 2, pp = i & 3;
+    const int col = col0 + 16 * half16 + 4 * pp;          // 4 consecutive columns = 8 bytes inside chunk col>>3
+    const int r_lo = krow0 + 4 * h + q, r_hi = r_lo + 8;
+    const char* a_lo = img + r_lo * 128 + (swz(r_lo, col >> 3) << 4) + (col & 7) * 2;
+    const char* a_hi = img + r_hi * 128 + (swz(r_hi, col >> 3) << 4) + (col & 7) * 2;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)a_lo);
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)a_hi);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// B operand (16 k x 32 cols) straight from global memory: column = matrix row (row0 + lane&31), k = 8 contiguous elements.
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ base, int ld, int row, int kchunk, int lane) {
+    return *(const bf16x8*)(base + (size_t)row * ld + (kchunk + (lane >> 5)) * 8);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f32_to_bf16(a[8 * s + j]);
+    return r;
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+struct AttnParams {
+    const bf16_t* qkv; int ld; const uint8_t* key_mask;
+    bf16_t* out; int ldo; float* lse;
+    const bf16_t* dout; bf16_t* dqkv; int lddqkv; float* delta;
+    int n_seq, S, heads, causal;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NT>   // number of 32-row tiles: S <= 32*NT
+__global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + NT * 32 * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int d = p.heads * 64;
+    const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+    stage_head(qb + d, p.ld, p.S, NT * 32, Ks, tid, NT * 64);
+    stage_head(qb + 2 * d, p.ld, p.S, NT * 32, Vs, tid, NT * 64);
+
+    const int q0 = wave * 32;
+    const int qi = q0 + (lane & 31);
+    const int qrow = qi < p.S ? qi : p.S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = gfrag(qb, p.ld, qrow, 2 * ks, lane);
+    __syncthreads();
+    if (q0 >= p.S) return;   // wave-uniform; no barrier follows
+
+    f32x16 st[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], st[kt], 0, 0, 0);
+    }
+    const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + acc_row(e, lane);
+            bool ok = key < p.S;
+            if (ok && km) ok = km[key] != 0;
+            if (p.causal) ok = ok && key <= qi;
+            st[kt][e] = ok ? st[kt][e] : -INFINITY;
+            mx = fmaxf(mx, st[kt][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;
+    const float c = 0.125f * LOG2E;     // head_dim^-0.5 (mer_lora.py:128-129), exp via exp2
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = exp2f((st[kt][e] - mx) * c);
+            st[kt][e] = pe;
+            l += pe;
+        }
+    l += __shfl_xor(l, 32, 64);
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Vs, kt * 32 + 16 * s, dt * 32, lane), pack8(st[kt], s),
+                                                                 ot[dt], 0, 0, 0);
+    }
+    if (qi < p.S) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = p.out + ((size_t)seq * p.S + qi) * p.ldo + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
+                *(uint2*)(orow + dd) = uint2{pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv),
+                                             pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv)};
+            }
+        if (p.lse && lane < 32) p.lse[((size_t)seq * p.heads + head) * p.S + qi] = mx * 0.125f + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: delta
+// delta[seq, head, q] = sum_d dO[q, d] * O[q, d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (seq*S + q)*heads + head ... one wave per (row, head)
+    const long total = (long)p.n_seq * p.S * p.heads;
+    if (item >= total) return;
+    const int head = item % p.heads;
+    const long row = item / p.heads;
+    const bf16_t* o = p.out + row * p.ldo + head * 64;
+    const bf16_t* g = p.dout + row * p.ldo + head * 64;
+    const float v = bf16_to_f32(o[lane]) * bf16_to_f32(g[lane]);
+    const float s = wave_sum(v);
+    if (lane == 0) {
+        const long seq = row / p.S, q = row % p.S;
+        p.delta[(seq * p.heads + head) * p.S + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+// Wave w owns key tile w (keys on the lane).  Per query tile: S = Q.K^T and dP = dO.V^T land as
+// [query rows (regs) x key columns (lanes)] and feed dV^T += dO^T.P and dK^T += Q^T.dS as B operands.
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Gs = smem + NT * 32 * 128;                 // dO
+    float* rowc = (float*)(smem + 2 * NT * 32 * 128);   // [2][NT*32]: lse, delta
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int d = p.heads * 64;
+    const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+    const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
+    stage_head(qb, p.ld, p.S, NT * 32, Qs, tid, NT * 64);
+    stage_head(gb, p.ldo, p.S, NT * 32, Gs, tid, NT * 64);
+    for (int t = tid; t < NT * 32; t += NT * 64) {
+        const size_t o = ((size_t)seq * p.heads + head) * p.S + t;
+        rowc[t] = t < p.S ? p.lse[o] : 0.f;
+        rowc[NT * 32 + t] = t < p.S ? p.delta[o] : 0.f;
+    }
+    const int k0 = wave * 32;
+    const int ki = k0 + (lane & 31);
+    const int krow = ki < p.S ? ki : p.S - 1;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = gfrag(qb + d, p.ld, krow, 2 * ks, lane);
+        vf[ks] = gfrag(qb + 2 * d, p.ld, krow, 2 * ks, lane);
+    }
+    __syncthreads();
+    if (k0 >= p.S) return;
+    const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
+    const bool key_ok = ki < p.S && (!km || km[ki] != 0);
+
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
+    const float c = 0.125f * LOG2E;
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 32 >= p.S) break;
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qt * 32, 2 * ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gs, qt * 32, 2 * ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+        f32x16 pm, ds;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = qt * 32 + acc_row(e, lane);
+            bool ok = key_ok && q < p.S;
+            if (p.causal) ok = ok && ki <= q;
+            const float pe = ok ? exp2f(s[e] * c - rowc[q] * LOG2E) : 0.f;
+            pm[e] = pe;
+            ds[e] = pe * (dp[e] - rowc[NT * 32 + q]) * 0.125f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Gs, qt * 32 + 16 * s2, dt * 32, lane), pack8(pm, s2), dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Qs, qt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dkt[dt], 0, 0, 0);
+            }
+    }
+    if (ki < p.S) {
+        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + ki) * p.lddqkv + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
+                *(uint2*)(drow + d + dd) = uint2{pack_bf16x2(dkt[dt][4 * g], dkt[dt][4 * g + 1]), pack_bf16x2(dkt[dt][4 * g + 2], dkt[dt][4 * g + 3])};
+                *(uint2*)(drow + 2 * d + dd) = uint2{pack_bf16x2(dvt[dt][4 * g], dvt[dt][4 * g + 1]), pack_bf16x2(dvt[dt][4 * g + 2], dvt[dt][4 * g + 3])};
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+// Wave w owns query tile w (queries on the lane).  S^T = K.Q^T and dP^T = V.dO^T land as
+// [key rows (regs) x query columns (lanes)]; dQ^T += K^T.dS^T.
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + NT * 32 * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int d = p.heads * 64;
+    const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+    const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
+    stage_head(qb + d, p.ld, p.S, NT * 32, Ks, tid, NT * 64);
+    stage_head(qb + 2 * d, p.ld, p.S, NT * 32, Vs, tid, NT * 64);
+    const int q0 = wave * 32;
+    const int qi = q0 + (lane & 31);
+    const int qrow = qi < p.S ? qi : p.S - 1;
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = gfrag(qb, p.ld, qrow, 2 * ks, lane);
+        gf[ks] = gfrag(gb, p.ldo, qrow, 2 * ks, lane);
+    }
+    const size_t so = ((size_t)seq * p.heads + head) * p.S + qrow;
+    const float lse = p.lse[so] * LOG2E, delta = p.delta[so];
+    __syncthreads();
+    if (q0 >= p.S) return;
+    const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
+    f32x16 dqt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+    const float c = 0.125f * LOG2E;
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt * 32 >= p.S) break;
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, 2 * ks, lane), gf[ks], dp, 0, 0, 0);
+        }
+        f32x16 ds;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + acc_row(e, lane);
+            bool ok = key < p.S && qi < p.S;
+            if (ok && km) ok = km[key] != 0;
+            if (p.causal) ok = ok && key <= qi;
+            const float pe = ok ? exp2f(s[e] * c - lse) : 0.f;
+            ds[e] = pe * (dp[e] - delta) * 0.125f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Ks, kt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dqt[dt], 0, 0, 0);
+    }
+    if (qi < p.S) {
+        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + qi) * p.lddqkv + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
+                *(uint2*)(drow + dd) = uint2{pack_bf16x2(dqt[dt][4 * g], dqt[dt][4 * g + 1]), pack_bf16x2(dqt[dt][4 * g + 2], dqt[dt][4 * g + 3])};
+            }
+    }
+}
+
+template <int NT>
+int launch_fwd(const AttnParams& p, hipStream_t s) {
+    constexpr int LDS = 2 * NT * 32 * 128;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS, s, p);
+    REID_CHECK_LAUNCH("reid_attn_fwd");
+    return REID_OK;
+}
+
+template <int NT>
+int launch_bwd(const AttnParams& p, hipStream_t s) {
+    constexpr int LDS1 = 2 * NT * 32 * 128 + 2 * NT * 32 * 4;
+    constexpr int LDS2 = 2 * NT * 32 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        attr_set = true;
+    }
+    const long items = (long)p.n_seq * p.S * p.heads;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, s, p);
+    REID_CHECK_LAUNCH("reid_attn_bwd(delta)");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS1, s, p);
+    REID_CHECK_LAUNCH("reid_attn_bwd(dkv)");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS2, s, p);
+    REID_CHECK_LAUNCH("reid_attn_bwd(dq)");
+    return REID_OK;
+}
+
+int check_common(const char* name, const void* qkv, int ld, int n_seq, int S, int heads) {
+    REID_CHECK_ARG(qkv != nullptr, "%s: null qkv", name);
+    REID_CHECK_ARG(n_seq > 0 && heads > 0 && S > 0 && S <= 224, "%s: S=%d must be in 1..224 (n_seq=%d heads=%d)", name, S, n_seq, heads);
+    REID_CHECK_ARG(ld >= 3 * heads * 64 && ld % 8 == 0, "%s: ld=%d must be >= 3*heads*64 and a multiple of 8", name, ld);
+    return REID_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_NT(nt, fn, ...)                \
+    switch (nt) {                               \
+        case 1: return fn<1>(__VA_ARGS__);      \
+        case 2: return fn<2>(__VA_ARGS__);      \
+        case 3: return fn<3>(__VA_ARGS__);      \
+        case 4: return fn<4>(__VA_ARGS__);      \
+        case 5: return fn<5>(__VA_ARGS__);      \
+        case 6: return fn<6>(__VA_ARGS__);      \
+        default: return fn<7>(__VA_ARGS__);     \
+    }
+
+extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mask, void* out, int32_t ldo, float* lse,
+                             int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream) {
+    int rc = check_common("reid_attn_fwd", qkv, ld, n_seq, S, heads);
+    if (rc) return rc;
+    REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal};
+    DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
+}
+
+extern "C" int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mask, const void* out, const void* dout,
+                             int32_t ldo, const float* lse, void* dqkv, int32_t lddqkv, float* delta_ws, int32_t n_seq,
+                             int32_t S, int32_t heads, int32_t causal, void* stream) {
+    int rc = check_common("reid_attn_bwd", qkv, ld, n_seq, S, heads);
+    if (rc) return rc;
+    REID_CHECK_ARG(out && dout && lse && dqkv && delta_ws, "reid_attn_bwd: null pointer");
+    REID_CHECK_ARG(ldo >= heads * 64 && ldo % 8 == 0 && lddqkv >= 3 * heads * 64 && lddqkv % 4 == 0, "reid_attn_bwd: ldo/lddqkv");
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, (float*)lse, (const bf16_t*)dout, (bf16_t*)dqkv, lddqkv,
+                 delta_ws, n_seq, S, heads, causal};
+    DISPATCH_NT((S + 31) / 32, launch_bwd, p, (hipStream_t)stream)
+}

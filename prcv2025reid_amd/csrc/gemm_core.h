@@ -1,0 +1,125 @@
+// Shared MFMA tile main loop of the gfx950 GEMM-shaped kernels (mer_gemm, cosine_topk).
+// See gemm.hip for the design notes.
+#pragma once
+#include "common.h"
+
+namespace gemmcore {
+
+// physical 16-byte chunk of logical chunk c in row `row` of a [rows][64] bf16 tile (128-byte rows).
+// Two rows share one 256-byte bank row; rows r and r+2 would otherwise collide on every ds_read_b128.
+__device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 1) & 7); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WM, int WN>
+struct Cfg {
+    static constexpr int NW = WM * WN;
+    static constexpr int NT = NW * 64;
+    static constexpr int TM = BM / WM / 16;          // 16-row activation sub-tiles per wave
+    static constexpr int TN = BN / WN / 16;          // 16-row weight sub-tiles per wave
+    static constexpr int A_BYTES = BM * 128;
+    static constexpr int B_BYTES = BN * 128;
+    static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static constexpr int A_INSTR = BM / 8 / NW;      // LDS-DMA wave-instructions per wave per tile
+    static constexpr int B_INSTR = BN / 8 / NW;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over waves");
+};
+
+// Stage one K-step of one operand: rows [row0, row0+ROWS) x 64 k (HALF: only logical chunks 0..3 are
+// meaningful; the other lanes re-load a valid chunk that is never read).
+template <int ROWS, int NW, bool HALF>
+__device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int ld, int row0, int row_max, int k0,
+                                      char* lds, int wave, int lane) {
+    constexpr int INSTR = ROWS / 8 / NW;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i) {
+        const int rblk = (i * NW + wave) * 8;
+        const int r = rblk + (lane >> 3);
+        int c = swz(r, lane & 7);
+        if (HALF) c &= 3;
+        int grow = row0 + r;
+        grow = grow < row_max ? grow : row_max;
+        const bf16_t* g = src + (size_t)grow * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + rblk * 128), 16, 0, 0);
+    }
+}
+
+
+// XCD-aware linear tile id: blocks b and b+8 share an XCD (one L2); every XCD gets a contiguous run
+// of tiles (bijective for any grid size, cdna_hip_programming.md section 5 "XCD swizzle").
+__device__ __forceinline__ int xcd_linear_block(int bid, int nwg) {
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+// acc[j][i] (+)= W[n0 + wn-slice + 16j .. , :] . X[m0 + wm-slice + 16i .. , :]^T over K (64-wide steps)
+// plus the optional low-rank pair over K2 (32-wide half steps).  MFMA rows = B-operand rows (n),
+// MFMA columns = A-operand rows (m): lane holds C[m = lane&15][n = 4*(lane>>4) + reg].
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                         const bf16_t* __restrict__ A2, int lda2, const bf16_t* __restrict__ B2, int ldb2,
+                                         int M, int N, int K, int K2, int m0, int n0, char* smem,
+                                         f32x4 (&acc)[Cfg<BM, BN, WM, WN>::TN][Cfg<BM, BN, WM, WN>::TM]) {
+    using C = Cfg<BM, BN, WM, WN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nk = K >> 6;
+    const int nk2 = A2 ? (K2 >> 5) : 0;
+    const int steps = nk + nk2;
+
+    auto issue = [&](int t, int buf) {
+        char* la = smem + buf * C::BUF_BYTES;
+        char* lb = la + C::A_BYTES;
+        if (t < nk) {
+            stage<BM, C::NW, false>(A, lda, m0, M - 1, t << 6, la, wave, lane);
+            stage<BN, C::NW, false>(B, ldb, n0, N - 1, t << 6, lb, wave, lane);
+        } else {
+            const int k2 = (t - nk) << 5;
+            stage<BM, C::NW, true>(A2, lda2, m0, M - 1, k2, la, wave, lane);
+            stage<BN, C::NW, true>(B2, ldb2, n0, N - 1, k2, lb, wave, lane);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf, int nks) {
+        const char* la = smem + buf * C::BUF_BYTES;
+        const char* lb = la + C::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < nks) {
+                bf16x8 af[C::TM], wf[C::TN];
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) {
+                    const int row = wm * (BM / WM) + i * 16 + frow;
+                    af[i] = *(const bf16x8*)(la + row * 128 + (swz(row, ks * 4 + fq) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    const int row = wn * (BN / WN) + j * 16 + frow;
+                    wf[j] = *(const bf16x8*)(lb + row * 128 + (swz(row, ks * 4 + fq) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();   // vmcnt(0) + barrier: tile 0 landed for every wave
+    int cur = 0;
+    for (int t = 0; t < steps - 1; ++t) {
+        issue(t + 1, cur ^ 1);
+        compute(cur, t < nk ? 2 : 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur, (steps - 1) < nk ? 2 : 1);
+}
+
+}  // namespace gemmcore

@@ -1,0 +1,528 @@
+// Head of the hot path on gfx950: small exact-fp32 GEMM, BN-neck, label-smoothed CE, SDM loss.
+// Shapes here are tiny (rows = P*K per GPU, or the global batch under data parallelism; D = 512),
+// so these kernels are HBM/latency bound: one wavefront per row, 16-byte coalesced accesses,
+// wave-shuffle reductions, fp32 throughout (the losses are compared with an fp32 oracle at 1e-3).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ sgemm
+// C[M,N] = act(alpha * sum_k A(m,k) B(k,n) + bias[n]) + beta * C, arbitrary element strides for A and B.
+// 64x64 tile, 256 threads, 4x4 outputs per thread, K step 16.
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                    int M, int N, int K, long sam, long sak, long sbk, long sbn, int ldc,
+                                                    float alpha, float beta, const float* __restrict__ bias, int act) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256;           // 1024 elements per operand tile
+            {   // A tile: choose the fast index along the contiguous stride
+                int mm, kk;
+                if (sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+                const int m = m0 + mm, k = k0 + kk;
+                As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+            }
+            {
+                int nn, kk;
+                if (sbk == 1) { kk = e & 15; nn = e >> 4; } else { nn = e & 63; kk = e >> 6; }
+                const int n = n0 + nn, k = k0 + kk;
+                Bs[kk][nn] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float v = alpha * acc[i][j];
+            if (bias) v += bias[n];
+            if (act == REID_ACT_GELU_ERF) v = gelu_erf_f(v);
+            else if (act == REID_ACT_QUICK_GELU) v = quick_gelu_f(v);
+            else if (act == REID_ACT_RELU) v = fmaxf(v, 0.f);
+            float* c = C + (size_t)m * ldc + n;
+            *c = beta == 0.f ? v : v + beta * *c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ BN-neck
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ldx, int rows, int D, int rows_per_block,
+                                                       float* __restrict__ sum, float* __restrict__ sqsum) {
+    // block = 64 columns x 4 row lanes; grid = (D/64, row splits)
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    float a = 0.f, b = 0.f;
+    if (c < D)
+        for (int r = r0 + rl; r < r1; r += 4) { const float v = x[(size_t)r * ldx + c]; a += v; b += v * v; }
+    s1[rl][threadIdx.x & 63] = a; s2[rl][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        const int t = threadIdx.x;
+        atomicAdd(sum + c, s1[0][t] + s1[1][t] + s1[2][t] + s1[3][t]);
+        atomicAdd(sqsum + c, s2[0][t] + s2[1][t] + s2[2][t] + s2[3][t]);
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, float count, int training,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean,
+                                   float* __restrict__ invstd, int D, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float mu, var;
+    if (training) {
+        mu = sum[c] / count;
+        var = fmaxf(sqsum[c] / count - mu * mu, 0.f);
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+    } else {
+        mu = running_mean[c]; var = running_var[c];
+    }
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+}
+
+constexpr int MAXV = 4;
+
+__global__ __launch_bounds__(256) void bnneck_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ y,
+                                                         bf16_t* __restrict__ yb, int ldy, float* __restrict__ rnorm, int rows,
+                                                         int D, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    f32x4 z[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            const f32x4 xv = *(const f32x4*)(x + (size_t)row * ldx + c * 4);
+            const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+            const f32x4 mu = *(const f32x4*)(mean + c * 4), is = *(const f32x4*)(invstd + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { z[i][e] = (xv[e] - mu[e]) * is[e] * g[e] + b[e]; s += z[i][e] * z[i][e]; }
+        }
+    }
+    const float rn = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    if (lane == 0) rnorm[row] = rn;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 o = z[i] * (rn * scale);
+            *(f32x4*)(y + (size_t)row * ldy + c * 4) = o;
+            if (yb) *(uint2*)(yb + (size_t)row * ldy + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bnneck_bwd1_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ rnorm, float* __restrict__ dz,
+                                                          float* __restrict__ sum_dz, float* __restrict__ sum_dz_xhat, int rows,
+                                                          int D, float scale) {
+    __shared__ float r1[4][MAXV * 256], r2[4][MAXV * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    const int nv = D >> 2;
+    f32x4 dzv[MAXV], xh[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { dzv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[i] = dzv[i]; }
+    if (row < rows) {
+        const float rn = rnorm[row];
+        f32x4 u[MAXV], g[MAXV];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + i * 64;
+            u[i] = f32x4{0.f, 0.f, 0.f, 0.f}; g[i] = u[i];
+            if (c < nv) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)row * ldx + c * 4);
+                const f32x4 gm = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+                const f32x4 mu = *(const f32x4*)(mean + c * 4), is = *(const f32x4*)(invstd + c * 4);
+                g[i] = *(const f32x4*)(dy + (size_t)row * lddy + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu[e]) * is[e];
+                    u[i][e] = (xh[i][e] * gm[e] + b[e]) * rn;       // unit vector
+                    dot += u[i][e] * g[i][e];
+                }
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dzv[i][e] = scale * rn * (g[i][e] - u[i][e] * dot);
+                *(f32x4*)(dz + (size_t)row * D + c * 4) = dzv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r1[w][(lane + i * 64) * 4 + e] = dzv[i][e];
+            r2[w][(lane + i * 64) * 4 + e] = dzv[i][e] * xh[i][e];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(sum_dz + c, r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c]);
+        atomicAdd(sum_dz_xhat + c, r2[0][c] + r2[1][c] + r2[2][c] + r2[3][c]);
+    }
+}
+
+__global__ void bnneck_bwd2_kernel(const float* __restrict__ dz, const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_dz,
+                                   const float* __restrict__ sum_dz_xhat, float count, int training, float* __restrict__ dx, int lddx,
+                                   int rows, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * D) return;
+    const int r = i / D, c = i % D;
+    const float is = invstd[c], g = gamma[c];
+    float v = dz[i];
+    if (training) {
+        const float xh = (x[(size_t)r * ldx + c] - mean[c]) * is;
+        v = v - sum_dz[c] / count - xh * sum_dz_xhat[c] / count;
+    }
+    dx[(size_t)r * lddx + c] = g * is * v;
+}
+
+// ------------------------------------------------------------------------------------------ CE with label smoothing
+__device__ __forceinline__ void row_softmax_stats(const float* __restrict__ z, int C, int lane, float& mx, float& se, float& sz) {
+    mx = -INFINITY; sz = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = z[c]; mx = fmaxf(mx, v); sz += v; }
+    mx = wave_max(mx); sz = wave_sum(sz);
+    se = 0.f;
+    for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
+    se = wave_sum(se);
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                     const uint8_t* __restrict__ valid, int rows, int C, float eps,
+                                                     float* __restrict__ row_loss, float* __restrict__ loss_sum) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long y = labels[row];
+    const bool ok = (!valid || valid[row]) && y >= 0 && y < C;
+    float loss = 0.f;
+    if (ok) {
+        const float* z = logits + (size_t)row * ld;
+        float mx, se, sz;
+        row_softmax_stats(z, C, lane, mx, se, sz);
+        const float lse = mx + logf(se);
+        loss = (1.f - eps) * (lse - z[y]) + eps * (lse - sz / C);
+    }
+    if (lane == 0) {
+        if (row_loss) row_loss[row] = loss;
+        if (ok) { atomicAdd(loss_sum, loss); atomicAdd(loss_sum + 1, 1.0f); }
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                                     const uint8_t* __restrict__ valid, int rows, int C, float eps,
+                                                     const float* __restrict__ grad_scale, float* __restrict__ dl, int lddl) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long y = labels[row];
+    const bool ok = (!valid || valid[row]) && y >= 0 && y < C;
+    float* d = dl + (size_t)row * lddl;
+    if (!ok) {
+        for (int c = lane; c < C; c += 64) d[c] = 0.f;
+        return;
+    }
+    const float* z = logits + (size_t)row * ld;
+    float mx, se, sz;
+    row_softmax_stats(z, C, lane, mx, se, sz);
+    const float gs = grad_scale[0], inv = 1.f / se;
+    for (int c = lane; c < C; c += 64) {
+        const float p = __expf(z[c] - mx) * inv;
+        d[c] = gs * (p - eps / C - (c == y ? 1.f - eps : 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SDM
+// Row statistics of one side of the similarity matrix S [R, Cn] (row-major): for rows that take part,
+// lse over participating columns, number of positives, mean positive score; accumulates the side's
+// loss sum and row count.  stat[r] = {lse, npos} is kept for the backward pass.
+__global__ __launch_bounds__(256) void sdm_side_kernel(const float* __restrict__ S, int ld, const int64_t* __restrict__ rlab,
+                                                       const int64_t* __restrict__ clab, const uint8_t* __restrict__ rvalid,
+                                                       const uint8_t* __restrict__ cvalid, int R, int Cn, float* __restrict__ stat,
+                                                       float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float lse = 0.f, npos = 0.f, loss = 0.f;
+    if (!rvalid || rvalid[row]) {
+        const float* s = S + (size_t)row * ld;
+        const long y = rlab[row];
+        float mx = -INFINITY, ps = 0.f;
+        for (int c = lane; c < Cn; c += 64)
+            if (!cvalid || cvalid[c]) {
+                const float v = fminf(fmaxf(s[c], -20.f), 20.f);
+                mx = fmaxf(mx, v);
+                if (clab[c] == y) { npos += 1.f; ps += v; }
+            }
+        mx = wave_max(mx); npos = wave_sum(npos); ps = wave_sum(ps);
+        if (npos > 0.f) {
+            float se = 0.f;
+            for (int c = lane; c < Cn; c += 64)
+                if (!cvalid || cvalid[c]) se += __expf(fminf(fmaxf(s[c], -20.f), 20.f) - mx);
+            se = wave_sum(se);
+            lse = mx + logf(se);
+            loss = lse - ps / npos;
+        }
+    }
+    if (lane == 0) {
+        stat[2 * row] = lse; stat[2 * row + 1] = npos;
+        if (npos > 0.f) { atomicAdd(acc, loss); atomicAdd(acc + 1, 1.0f); }
+    }
+}
+
+__global__ void sdm_finalize_kernel(const float* __restrict__ acc, float* __restrict__ result) {
+    // acc = {sum_q2g, cnt_q2g, sum_g2q, cnt_g2q}
+    const float a = acc[1] > 0.f ? acc[0] / acc[1] : 0.f;
+    const float b = acc[3] > 0.f ? acc[2] / acc[3] : 0.f;
+    const bool any = acc[1] > 0.f;
+    result[0] = any ? 0.5f * (a + b) : 0.f;
+    result[1] = any ? 1.f : 0.f;
+}
+
+// dS in place: S[i,j] <- g*0.5*[ 1[np_i>0]/cntR*(softmax_row - y/np_i) + 1[np_j>0]/cntC*(softmax_col - y/np_j) ]
+__global__ void sdm_ds_kernel(float* __restrict__ S, int ld, const int64_t* __restrict__ qlab, const int64_t* __restrict__ glab,
+                              const uint8_t* __restrict__ qvalid, const uint8_t* __restrict__ gvalid, int N, int Mg,
+                              const float* __restrict__ rstat, const float* __restrict__ cstat, const float* __restrict__ acc,
+                              const float* __restrict__ gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Mg) return;
+    const int r = i / Mg, c = i % Mg;
+    float* p = S + (size_t)r * ld + c;
+    float out = 0.f;
+    if ((!qvalid || qvalid[r]) && (!gvalid || gvalid[c]) && acc[1] > 0.f) {
+        const float raw = *p;
+        const float v = fminf(fmaxf(raw, -20.f), 20.f);
+        const float y = qlab[r] == glab[c] ? 1.f : 0.f;
+        const float npr = rstat[2 * r + 1], npc = cstat[2 * c + 1];
+        float t = 0.f;
+        if (npr > 0.f) t += (__expf(v - rstat[2 * r]) - y / npr) / acc[1];
+        if (npc > 0.f && acc[3] > 0.f) t += (__expf(v - cstat[2 * c]) - y / npc) / acc[3];
+        out = (raw > -20.f && raw < 20.f) ? 0.5f * gscale[0] * t : 0.f;
+    }
+    *p = out;
+}
+
+// y = x / max(||x||, eps): dx (+)= (dy - y (y.dy)) / max(||x||, eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                         float* __restrict__ dx, int lddx, int rows, int D, float eps,
+                                                         int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    f32x4 xv[MAXV], gv[MAXV];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[i] = xv[i];
+        if (c < nv) {
+            xv[i] = *(const f32x4*)(x + (size_t)row * ldx + c * 4);
+            gv[i] = *(const f32x4*)(dy + (size_t)row * lddy + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ss += xv[i][e] * xv[i][e]; dot += xv[i][e] * gv[i][e]; }
+        }
+    }
+    const float n = fmaxf(sqrtf(wave_sum(ss)), eps);
+    const float rn = 1.f / n;
+    dot = wave_sum(dot) * rn * rn;      // (y.dy)/n with y = x/n  ->  x.dy / n^2
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            float* d = dx + (size_t)row * lddx + c * 4;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (gv[i][e] - xv[i][e] * dot) * rn;
+            if (accumulate) o += *(const f32x4*)d;
+            *(f32x4*)d = o;
+        }
+    }
+}
+
+int launch_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn, int ldc,
+                 float alpha, float beta, const float* bias, int act, hipStream_t s) {
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc,
+                       alpha, beta, bias, act);
+    REID_CHECK_LAUNCH("reid_sgemm");
+    return REID_OK;
+}
+
+}  // namespace
+
+extern "C" int reid_sgemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak,
+                          int64_t sbk, int64_t sbn, int32_t ldc, float alpha, float beta, const float* bias, int32_t act,
+                          void* stream) {
+    REID_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N, "reid_sgemm: bad args");
+    REID_CHECK_ARG(act >= 0 && act <= REID_ACT_RELU, "reid_sgemm: act=%d", act);
+    return launch_sgemm(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, act, (hipStream_t)stream);
+}
+
+extern "C" int reid_bnneck_stats(const float* x, int32_t ldx, int32_t rows, int32_t D, float* sum, float* sqsum, void* stream) {
+    REID_CHECK_ARG(x && sum && sqsum && rows > 0 && D > 0, "reid_bnneck_stats: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sum, 0, D * sizeof(float), s);
+    (void)hipMemsetAsync(sqsum, 0, D * sizeof(float), s);
+    int splits = (rows + 63) / 64; if (splits > 64) splits = 64;
+    const int rpb = (rows + splits - 1) / splits;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((D + 63) / 64, splits), dim3(256), 0, s, x, ldx, rows, D, rpb, sum, sqsum);
+    REID_CHECK_LAUNCH("reid_bnneck_stats");
+    return REID_OK;
+}
+
+extern "C" int reid_bnneck_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, const float* sum, const float* sqsum, float count, int32_t training, float* y,
+                               void* y_bf16, int32_t ldy, float* mean, float* invstd, float* rnorm, int32_t rows, int32_t D,
+                               float eps, float momentum, float scale, void* stream) {
+    REID_CHECK_ARG(x && gamma && beta && y && mean && invstd && rnorm, "reid_bnneck_fwd: null pointer");
+    REID_CHECK_ARG(rows > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV && ldx % 4 == 0 && ldy % 4 == 0, "reid_bnneck_fwd: shape");
+    REID_CHECK_ARG(training ? (sum && sqsum && count > 0) : (running_mean && running_var), "reid_bnneck_fwd: statistics missing");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, sum, sqsum, count, training, running_mean,
+                       running_var, mean, invstd, D, eps, momentum);
+    REID_CHECK_LAUNCH("reid_bnneck_fwd(finalize)");
+    hipLaunchKernelGGL(bnneck_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, gamma, beta, mean, invstd, y, (bf16_t*)y_bf16,
+                       ldy, rnorm, rows, D, scale);
+    REID_CHECK_LAUNCH("reid_bnneck_fwd");
+    return REID_OK;
+}
+
+extern "C" int reid_bnneck_bwd_p1(const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* gamma, const float* beta,
+                                  const float* mean, const float* invstd, const float* rnorm, float* dz, float* sum_dz,
+                                  float* sum_dz_xhat, int32_t rows, int32_t D, float scale, void* stream) {
+    REID_CHECK_ARG(dy && x && gamma && beta && mean && invstd && rnorm && dz && sum_dz && sum_dz_xhat, "reid_bnneck_bwd_p1: null pointer");
+    REID_CHECK_ARG(rows > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "reid_bnneck_bwd_p1: shape");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(sum_dz, 0, D * sizeof(float), s);
+    (void)hipMemsetAsync(sum_dz_xhat, 0, D * sizeof(float), s);
+    hipLaunchKernelGGL(bnneck_bwd1_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, invstd, rnorm, dz,
+                       sum_dz, sum_dz_xhat, rows, D, scale);
+    REID_CHECK_LAUNCH("reid_bnneck_bwd_p1");
+    return REID_OK;
+}
+
+extern "C" int reid_bnneck_bwd_p2(const float* dz, const float* x, int32_t ldx, const float* gamma, const float* mean,
+                                  const float* invstd, const float* sum_dz, const float* sum_dz_xhat, float count, int32_t training,
+                                  float* dx, int32_t lddx, int32_t rows, int32_t D, void* stream) {
+    REID_CHECK_ARG(dz && x && gamma && mean && invstd && sum_dz && sum_dz_xhat && dx && rows > 0 && count > 0, "reid_bnneck_bwd_p2: bad args");
+    const long n = (long)rows * D;
+    hipLaunchKernelGGL(bnneck_bwd2_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz, x, ldx, gamma, mean, invstd,
+                       sum_dz, sum_dz_xhat, count, training, dx, lddx, rows, D);
+    REID_CHECK_LAUNCH("reid_bnneck_bwd_p2");
+    return REID_OK;
+}
+
+extern "C" int reid_ce_ls_fwd(const float* logits, int32_t ld, const int64_t* labels, const uint8_t* valid, int32_t rows, int32_t C,
+                              float smoothing, float* row_loss, float* loss_sum, void* stream) {
+    REID_CHECK_ARG(logits && labels && loss_sum && rows > 0 && C > 0 && ld >= C, "reid_ce_ls_fwd: bad args");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, valid, rows, C, smoothing,
+                       row_loss, loss_sum);
+    REID_CHECK_LAUNCH("reid_ce_ls_fwd");
+    return REID_OK;
+}
+
+extern "C" int reid_ce_ls_bwd(const float* logits, int32_t ld, const int64_t* labels, const uint8_t* valid, int32_t rows, int32_t C,
+                              float smoothing, const float* grad_scale, float* dlogits, int32_t lddl, void* stream) {
+    REID_CHECK_ARG(logits && labels && grad_scale && dlogits && rows > 0 && C > 0 && ld >= C && lddl >= C, "reid_ce_ls_bwd: bad args");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, valid, rows, C, smoothing,
+                       grad_scale, dlogits, lddl);
+    REID_CHECK_LAUNCH("reid_ce_ls_bwd");
+    return REID_OK;
+}
+
+// workspace (floats): S[N*Mg] | ST[Mg*N] | qn[N*1024] | gn[Mg*1024] | rstat[2N] | cstat[2Mg] | acc[8] | tmp[max(N,Mg)*1024]
+static inline int64_t sdm_off_st(int N, int Mg) { return (int64_t)N * Mg; }
+extern "C" int64_t reid_sdm_ws_floats(int32_t N, int32_t Mg) {
+    return 2 * (int64_t)N * Mg + (int64_t)(N + Mg) * 1024 + 2 * (N + Mg) + 8 + (int64_t)(N > Mg ? N : Mg) * 1024;
+}
+
+extern "C" int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label, const int64_t* g_label,
+                            const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg, int32_t D, float tau, float* ws,
+                            float* result, void* stream) {
+    REID_CHECK_ARG(q && g && q_label && g_label && ws && result, "reid_sdm_fwd: null pointer");
+    REID_CHECK_ARG(N > 0 && Mg > 0 && D % 4 == 0 && D <= 1024, "reid_sdm_fwd: shape N=%d Mg=%d D=%d", N, Mg, D);
+    hipStream_t s = (hipStream_t)stream;
+    const float t = fminf(fmaxf(tau, 0.15f), 0.5f);       // models/sdm_loss.py:28
+    float* S = ws; float* ST = S + (size_t)N * Mg; float* qn = ST + (size_t)N * Mg; float* gn = qn + (size_t)N * 1024;
+    float* rstat = gn + (size_t)Mg * 1024; float* cstat = rstat + 2 * N; float* acc = cstat + 2 * Mg;
+    (void)hipMemsetAsync(acc, 0, 4 * sizeof(float), s);
+    int rc;
+    if ((rc = reid_l2norm_rows(q, ldq, qn, nullptr, D, N, D, 1e-8f, 1.0f, stream))) return rc;
+    if ((rc = reid_l2norm_rows(g, ldg, gn, nullptr, D, Mg, D, 1e-8f, 1.0f, stream))) return rc;
+    if ((rc = launch_sgemm(qn, gn, S, N, Mg, D, D, 1, 1, D, Mg, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
+    if ((rc = launch_sgemm(gn, qn, ST, Mg, N, D, D, 1, 1, D, N, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(sdm_side_kernel, dim3((N + 3) / 4), dim3(256), 0, s, S, Mg, q_label, g_label, q_valid, g_valid, N, Mg, rstat, acc);
+    REID_CHECK_LAUNCH("reid_sdm_fwd(q2g)");
+    hipLaunchKernelGGL(sdm_side_kernel, dim3((Mg + 3) / 4), dim3(256), 0, s, ST, N, g_label, q_label, g_valid, q_valid, Mg, N, cstat, acc + 2);
+    REID_CHECK_LAUNCH("reid_sdm_fwd(g2q)");
+    hipLaunchKernelGGL(sdm_finalize_kernel, dim3(1), dim3(1), 0, s, acc, result);
+    REID_CHECK_LAUNCH("reid_sdm_fwd(finalize)");
+    return REID_OK;
+}
+
+extern "C" int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label, const int64_t* g_label,
+                            const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg, int32_t D, float tau, const float* ws,
+                            const float* gscale, float* dq, int32_t lddq, float* dg, int32_t lddg, void* stream) {
+    REID_CHECK_ARG(q && g && ws && gscale && dq && dg, "reid_sdm_bwd: null pointer");
+    REID_CHECK_ARG(N > 0 && Mg > 0 && D % 4 == 0 && D <= 1024, "reid_sdm_bwd: shape");
+    hipStream_t s = (hipStream_t)stream;
+    const float t = fminf(fmaxf(tau, 0.15f), 0.5f);
+    float* S = (float*)ws; float* ST = S + (size_t)N * Mg; float* qn = ST + (size_t)N * Mg; float* gn = qn + (size_t)N * 1024;
+    float* rstat = gn + (size_t)Mg * 1024; float* cstat = rstat + 2 * N; float* acc = cstat + 2 * Mg;
+    const long n = (long)N * Mg;
+    hipLaunchKernelGGL(sdm_ds_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, S, Mg, q_label, g_label, q_valid, g_valid, N, Mg, rstat,
+                       cstat, acc, gscale);
+    REID_CHECK_LAUNCH("reid_sdm_bwd(ds)");
+    // dqn = dS . gn / tau into the scratch region [N, D], then dgn [Mg, D]
+    float* tmp = acc + 8;
+    int rc;
+    if ((rc = launch_sgemm(S, gn, tmp, N, D, Mg, Mg, 1, D, 1, D, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, q, ldq, tmp, D, dq, lddq, N, D, 1e-8f, 1);
+    REID_CHECK_LAUNCH("reid_sdm_bwd(dq)");
+    // dgn = dS^T . qn / tau : A(m=j,k=i) = S[i*Mg + j] -> sam = 1, sak = Mg
+    if ((rc = launch_sgemm(S, qn, tmp, Mg, D, N, 1, Mg, D, 1, D, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((Mg + 3) / 4), dim3(256), 0, s, g, ldg, tmp, D, dg, lddg, Mg, D, 1e-8f, 1);
+    REID_CHECK_LAUNCH("reid_sdm_bwd(dg)");
+    return REID_OK;
+}

@@ -1,0 +1,299 @@
+// Cosine retrieval with exact top-k on gfx950 (reference: train.py:499,463; eval_mm_protocol.py:50-53,
+// 401-423): sim = Q.G^T on L2-normalised rows, ranking by (score desc, index asc).
+//
+// The 10k x 200k similarity matrix (8 GB in fp32) is never written.  Three phases:
+//   A  threshold: the bf16 MFMA tile GEMM scores every query against a small gallery sample and keeps
+//      the scores; one wavefront per query then finds the k-th best sample score s_k (LDS bitonic
+//      select) and sets thr[q] = s_k - 2*eps.  eps = 2^-8 bounds |bf16 score - fp32 score| for unit
+//      rows, so every member of the true top-k (ties included) scores >= thr in bf16.
+//   B  filter: the same MFMA GEMM over the whole gallery; the epilogue appends (score, index) of every
+//      entry >= thr[q] to the query's candidate list (global atomic counter; ~0.1 % of entries pass).
+//   C  select: per query, candidates are re-scored in fp32 from the fp32 rows (bit-compatible with a
+//      k-ordered fp32 dot product is not promised; the ORDER is: the fp32 score decides, index breaks
+//      ties) and the best k are extracted in LDS.
+// A query whose list overflowed is flagged (out_idx[q][0] = -2) and handled by the caller's exact
+// fallback (brute-force kernel below), so the result never silently degrades.
+#include "gemm_core.h"
+
+namespace {
+
+using namespace gemmcore;
+
+constexpr float EPS_BF16 = 0.00390625f * 1.01f;   // 2^-8 (+1 %): |q~.g~ - q.g| for unit q, g rounded to bf16
+
+struct TopkParams {
+    const bf16_t* Q; const bf16_t* G;
+    int Nq, Ng, D;
+    int g_begin, g_end;            // gallery slice scored by this launch
+    const int32_t* exq; const int32_t* exg;
+    const float* thr;              // [Nq] or null (phase A: keep everything)
+    float* dense; int ld_dense;    // phase A: dense scores [Nq, g_end-g_begin]
+    int32_t* cand_idx; float* cand_score; int32_t* cand_cnt; int cap;   // phase B
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN, bool DENSE>
+__global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) {
+    using C = Cfg<BM, BN, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // query tiles fastest: concurrently running blocks share a gallery panel in L2
+    const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
+    const int tn = lin / p.tiles_m, tm = lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = p.g_begin + tn * BN;
+    f32x4 acc[C::TN][C::TM];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // no low-rank pair: K2 = 0 (non-null dummies keep the staging code free of constant-null pointers)
+    mainloop<BM, BN, WM, WN>(p.Q, p.D, p.G, p.D, p.Q, p.D, p.G, p.D, p.Nq, p.g_end, p.D, 0, m0, n0, smem, acc);
+    const int mrow = lane & 15, ncol4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + mrow;
+        const bool mok = m < p.Nq;
+        const int mc = mok ? m : 0;
+        const float th = DENSE ? -INFINITY : p.thr[mc];
+        const int eq = p.exq ? p.exq[mc] : -1;
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 16 + ncol4;
+            f32x4 v = acc[j][i];
+            if (eq >= 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.g_end && p.exg[n + e] == eq) v[e] = -1e9f;
+            }
+            if (DENSE) {
+                if (mok) {
+                    float* d = p.dense + (size_t)m * p.ld_dense + (n - p.g_begin);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.g_end) d[e] = v[e];
+                }
+            } else {
+                const bool any = mok && (v[0] >= th || v[1] >= th || v[2] >= th || v[3] >= th);
+                if (any) {
+                    for (int e = 0; e < 4; ++e) {
+                        if (v[e] >= th && n + e < p.g_end) {
+                            const int slot = atomicAdd(p.cand_cnt + m, 1);
+                            if (slot < p.cap) {
+                                p.cand_idx[(size_t)m * p.cap + slot] = n + e;
+                                p.cand_score[(size_t)m * p.cap + slot] = v[e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// phase A tail: k-th largest of each row of dense [Nq, n] (n <= 4096) -> thr[q] = kth - 2 eps
+__global__ __launch_bounds__(256) void kth_kernel(const float* __restrict__ dense, int ld, int n, int k, float* __restrict__ thr, int Nq) {
+    extern __shared__ float sm[];       // [4][n]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= Nq) return;
+    volatile float* v = sm + (size_t)w * n;
+    for (int i = lane; i < n; i += 64) v[i] = dense[(size_t)q * ld + i];
+    // k rounds of wave-wide arg-max extraction (k is small: 10..100)
+    float kth = -INFINITY;
+    const int rounds = k < n ? k : n;
+    for (int r = 0; r < rounds; ++r) {
+        float best = -INFINITY; int bi = -1;
+        for (int i = lane; i < n; i += 64) if (v[i] > best) { best = v[i]; bi = i; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+        }
+        kth = best;
+        if (bi >= 0 && (bi & 63) == lane) v[bi] = -INFINITY;
+    }
+    if (lane == 0) thr[q] = (rounds < k ? -INFINITY : kth - 2.f * EPS_BF16);
+}
+
+// phase C: exact fp32 re-score of the candidates + top-k by (score desc, index asc)
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int D,
+                                                     const int32_t* __restrict__ exq, const int32_t* __restrict__ exg,
+                                                     const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ cand_cnt,
+                                                     int cap, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                     int Nq) {
+    extern __shared__ char sm2[];
+    volatile float* sc = (volatile float*)sm2;                  // [cap]
+    volatile int32_t* ix = (volatile int32_t*)(sc + cap);       // [cap]
+    float* qrow = (float*)((float*)sm2 + 2 * cap);         // [D]
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cnt = cand_cnt[q];
+    if (cnt > cap) {                          // overflow: caller must take the exact fallback
+        if (tid == 0) { out_idx[(size_t)q * k] = -2; out_score[(size_t)q * k] = 0.f; }
+        return;
+    }
+    for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
+    __syncthreads();
+    const int eq = exq ? exq[q] : -1;
+    for (int c = w; c < cnt; c += 4) {
+        const int gi = cand_idx[(size_t)q * cap + c];
+        const float* g = Gf + (size_t)gi * D;
+        float s = 0.f;
+        for (int i = lane * 4; i < D; i += 256) {
+            const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
+            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+        s = wave_sum(s);
+        if (eq >= 0 && exg[gi] == eq) s = -1e9f;
+        if (lane == 0) { sc[c] = s; ix[c] = gi; }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY; int bi = 0x7fffffff, bpos = -1;
+        for (int c = lane; c < cnt; c += 64) {
+            const float s = sc[c]; const int gi = ix[c];
+            if (gi >= 0 && (s > best || (s == best && gi < bi))) { best = s; bi = gi; bpos = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64); const int op = __shfl_xor(bpos, o, 64);
+            if (op >= 0 && (bpos < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; bpos = op; }
+        }
+        if (lane == 0) {
+            out_idx[(size_t)q * k + r] = bpos >= 0 ? bi : -1;
+            out_score[(size_t)q * k + r] = bpos >= 0 ? best : -INFINITY;
+        }
+        if (bpos >= 0 && (bpos & 63) == lane) ix[bpos] = -1;
+    }
+}
+
+// exact brute force for flagged queries: one block per query, fp32 throughout
+__global__ __launch_bounds__(256) void brute_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng, int D,
+                                                    const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int k,
+                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ scratch) {
+    const int q = blockIdx.x;
+    if (out_idx[(size_t)q * k] != -2) return;
+    __shared__ float qrow[1024];
+    __shared__ float rbest[4]; __shared__ int ridx[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
+    __syncthreads();
+    float* sc = scratch + (size_t)q * Ng;
+    const int eq = exq ? exq[q] : -1;
+    for (int gi = w; gi < Ng; gi += 4) {
+        const float* g = Gf + (size_t)gi * D;
+        float s = 0.f;
+        for (int i = lane * 4; i < D; i += 256) {
+            const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
+            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+        s = wave_sum(s);
+        if (eq >= 0 && exg[gi] == eq) s = -1e9f;
+        if (lane == 0) sc[gi] = s;
+    }
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int gi = tid; gi < Ng; gi += 256) {
+            const float s = sc[gi];
+            if (s > best || (s == best && gi < bi)) { best = s; bi = gi; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { rbest[w] = best; ridx[w] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 4; ++i)
+                if (rbest[i] > rbest[0] || (rbest[i] == rbest[0] && ridx[i] < ridx[0])) { rbest[0] = rbest[i]; ridx[0] = ridx[i]; }
+            const bool ok = ridx[0] != 0x7fffffff;
+            out_idx[(size_t)q * k + r] = ok ? ridx[0] : -1;
+            out_score[(size_t)q * k + r] = ok ? rbest[0] : -INFINITY;
+            if (ok) sc[ridx[0]] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int SAMPLE = 4096;
+inline int cap_for(int Ng, int k) {
+    // expected survivors ~ k*Ng/SAMPLE (the sample's k-th best is about the (k*Ng/SAMPLE)-th best overall); 4x head-room
+    long c = 4L * k * ((Ng + SAMPLE - 1) / SAMPLE) + 64;
+    if (c < 256) c = 256;
+    if (c > 8192) c = 8192;
+    return (int)c;
+}
+
+}  // namespace
+
+extern "C" int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k) {
+    const int64_t cap = cap_for(Ng, k);
+    const int64_t ns = Ng < SAMPLE ? Ng : SAMPLE;
+    // thr[Nq] | cnt[Nq] | cand_idx[Nq*cap] | cand_score[Nq*cap] | dense[Nq*ns]
+    return (int64_t)Nq * 8 + (int64_t)Nq * cap * 8 + (int64_t)Nq * ns * 4 + 256;
+}
+
+extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf, int32_t Nq, int32_t Ng,
+                                int32_t D, int32_t k, const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
+                                float* out_score, void* stream) {
+    REID_CHECK_ARG(Q_bf16 && G_bf16 && Qf && Gf && ws && out_idx && out_score, "reid_cosine_topk: null pointer");
+    REID_CHECK_ARG(Nq > 0 && Ng > 0 && k > 0 && k <= Ng && k <= 1024, "reid_cosine_topk: Nq=%d Ng=%d k=%d", Nq, Ng, k);
+    REID_CHECK_ARG(D % 64 == 0 && D <= 1024, "reid_cosine_topk: D=%d must be a multiple of 64, <= 1024", D);
+    REID_CHECK_ARG((exclude_q == nullptr) == (exclude_g == nullptr), "reid_cosine_topk: exclude_q and exclude_g go together");
+    hipStream_t s = (hipStream_t)stream;
+    const int cap = cap_for(Ng, k);
+    const int ns = Ng < SAMPLE ? Ng : SAMPLE;
+    float* thr = (float*)ws;
+    int32_t* cnt = (int32_t*)(thr + Nq);
+    int32_t* cidx = cnt + Nq;
+    float* cscore = (float*)(cidx + (size_t)Nq * cap);
+    float* dense = cscore + (size_t)Nq * cap;
+    constexpr int BM = 128, BN = 128;
+    using C = Cfg<BM, BN, 2, 2>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr_set = true; }
+    TopkParams p{};
+    p.Q = (const bf16_t*)Q_bf16; p.G = (const bf16_t*)G_bf16; p.Nq = Nq; p.Ng = Ng; p.D = D;
+    p.exq = exclude_q; p.exg = exclude_g; p.cap = cap;
+    p.tiles_m = (Nq + BM - 1) / BM;
+    // phase A: sample = first ns gallery rows, dense scores, k-th best -> thr
+    p.g_begin = 0; p.g_end = ns; p.thr = nullptr; p.dense = dense; p.ld_dense = ns;
+    p.tiles_n = (ns + BN - 1) / BN;
+    hipLaunchKernelGGL((score_kernel<BM, BN, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    REID_CHECK_LAUNCH("reid_cosine_topk(sample)");
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SAMPLE * 4); attr2 = true; }
+    hipLaunchKernelGGL(kth_kernel, dim3((Nq + 3) / 4), dim3(256), 4 * ns * sizeof(float), s, dense, ns, ns, k, thr, Nq);
+    REID_CHECK_LAUNCH("reid_cosine_topk(kth)");
+    // phase B: filter the whole gallery
+    (void)hipMemsetAsync(cnt, 0, (size_t)Nq * sizeof(int32_t), s);
+    p.g_begin = 0; p.g_end = Ng; p.thr = thr; p.dense = nullptr;
+    p.cand_idx = cidx; p.cand_score = cscore; p.cand_cnt = cnt;
+    p.tiles_n = (Ng + BN - 1) / BN;
+    hipLaunchKernelGGL((score_kernel<BM, BN, 2, 2, false>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    REID_CHECK_LAUNCH("reid_cosine_topk(filter)");
+    // phase C
+    const size_t lds = (size_t)cap * 8 + (size_t)D * 4;
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 1024 * 4); attr3 = true; }
+    hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cnt, cap, k, out_idx, out_score, Nq);
+    REID_CHECK_LAUNCH("reid_cosine_topk(select)");
+    return REID_OK;
+}
+
+/* Exact fp32 pass for queries flagged -2 by reid_cosine_topk (candidate overflow).  scratch: Nq*Ng floats. */
+extern "C" int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                                      const int32_t* exclude_q, const int32_t* exclude_g, float* scratch, int32_t* out_idx,
+                                      float* out_score, void* stream) {
+    REID_CHECK_ARG(Qf && Gf && scratch && out_idx && out_score && Nq > 0 && Ng > 0 && k > 0 && k <= Ng && D % 4 == 0 && D <= 1024,
+                   "reid_cosine_topk_exact: bad args");
+    hipLaunchKernelGGL(brute_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, out_score, scratch);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact");
+    return REID_OK;
+}

@@ -1,0 +1,330 @@
+// Row-wise HBM-bound kernels for gfx950: LayerNorm fwd/bwd, patch extraction, CLS rows, casts,
+// row gather, L2 normalisation.  One 64-lane wavefront owns one row; every global access is a
+// 16-byte (float4 / 8 x bf16) coalesced load or store; reductions are wave shuffles only.
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------- error plumbing (shared by all files)
+static thread_local char g_err[512] = "";
+void reid_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* reid_last_error(void) { return g_err; }
+extern "C" int reid_version(void) { return 100; }
+extern "C" int reid_check_device(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        reid_set_error("reid_check_device: hipGetDeviceProperties(%d) failed", dev);
+        return REID_ERR_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        reid_set_error("reid_check_device: device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        return REID_ERR_DEVICE;
+    }
+    return REID_OK;
+}
+
+namespace {
+
+constexpr int MAXV = 4;   // float4 vectors per lane: cols <= 64*4*4 = 1024
+
+// ---------------------------------------------------------------- LayerNorm forward
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ row_index,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16_t* __restrict__ yb, float* __restrict__ yf, int ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t src = row_index ? (size_t)row_index[row] : (size_t)row;
+    const float* xr = x + src * ldx;
+    const int nv = cols >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mu = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / cols + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = *(const f32x4*)(gamma + c * 4);
+            const f32x4 b = *(const f32x4*)(beta + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+            if (yf) *(f32x4*)(yf + (size_t)row * ldy + c * 4) = o;
+            if (yb) *(uint2*)(yb + (size_t)row * ldy + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                     const int32_t* __restrict__ row_index, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     bf16_t* __restrict__ dxb, int lddx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t xrow = row_index ? (size_t)row_index[row] : (size_t)row;
+    const float* xr = x + xrow * ldx;
+    const float mu = mean[row], rs = rstd[row];
+    const int nv = cols >> 2;
+    f32x4 xh[MAXV], g[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; g[i] = xh[i];
+        if (c < nv) {
+            const f32x4 xv = *(const f32x4*)(xr + c * 4);
+            const f32x4 gm = *(const f32x4*)(gamma + c * 4);
+            f32x4 d;
+            if (DY_BF16) {
+                const bf16x4 t = *(const bf16x4*)((const bf16_t*)dy + (size_t)row * lddy + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = bf16_to_f32((bf16_t)t[e]);
+            } else {
+                d = *(const f32x4*)((const float*)dy + (size_t)row * lddy + c * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (xv[e] - mu) * rs;
+                if (dgamma) atomicAdd(dgamma + c * 4 + e, d[e] * xh[i][e]);
+                if (dbeta) atomicAdd(dbeta + c * 4 + e, d[e]);
+                g[i][e] = d[e] * gm[e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / cols, m2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - m1 - xh[i][e] * m2);
+            if (dres) {
+                const f32x4 r = *(const f32x4*)(dres + xrow * lddx + c * 4);
+                o += r;
+            }
+            *(f32x4*)(dx + xrow * lddx + c * 4) = o;
+            if (dxb) *(uint2*)(dxb + xrow * lddx + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
+// ---------------------------------------------------------------- patch extraction (im2col, k = s = patch)
+// one thread = 8 consecutive pixels of one patch row -> one 16-byte bf16 store
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n_img, int H,
+                                                     int W, int P, int cin) {
+    const int gw = W / P, gh = H / P;
+    const int kc = cin * P * P;                    // columns of the patch matrix
+    const int chunks_per_row = kc / 8;
+    const long total = (long)n_img * gh * gw * chunks_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = i % chunks_per_row;
+        const long prow = i / chunks_per_row;                 // patch-matrix row
+        const int pw = prow % gw, ph = (prow / gw) % gh;
+        const long b = prow / (gw * gh);
+        const int k = ch * 8;                                  // column = c*P*P + py*P + px
+        const int c = k / (P * P), py = (k / P) % P, px = k % P;
+        const size_t base = ((size_t)b * 3) * H * W + (size_t)(ph * P + py) * W + pw * P + px;
+        float v[8];
+        if (cin == 3) {
+            const float* s = img + base + (size_t)c * H * W;
+            const f32x4 a = *(const f32x4*)s, bb = *(const f32x4*)(s + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = bb[e]; }
+        } else {   // 3-channel input to a 1-channel embed: channel mean first (patch_embeds.py:63-65)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int cc = 0; cc < 3; ++cc) {
+                const float* s = img + base + (size_t)cc * H * W;
+                const f32x4 a = *(const f32x4*)s, bb = *(const f32x4*)(s + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += bb[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / 3.0f;
+        }
+        uint4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *(uint4*)(out + (size_t)prow * kc + k) = o;
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos0, float* __restrict__ x, int ldx,
+                                int n_img, int tokens, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nv = cols >> 2;
+    if (i >= n_img * nv) return;
+    const int b = i / nv, c = i % nv;
+    const f32x4 a = *(const f32x4*)(cls + c * 4), p = *(const f32x4*)(pos0 + c * 4);
+    *(f32x4*)(x + (size_t)b * tokens * ldx + c * 4) = a + p;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(s + i * 8), b = *(const f32x4*)(s + i * 8 + 4);
+        *(uint4*)(d + i * 8) = uint4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) d[n8 * 8 + threadIdx.x] = f32_to_bf16(s[n8 * 8 + threadIdx.x]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = bf16_to_f32(s[i]);
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const int32_t* __restrict__ index, float* __restrict__ dst,
+                                   int ldd, int rows, int cols) {
+    const int nv = cols >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * nv) return;
+    const int r = i / nv, c = i % nv;
+    *(f32x4*)(dst + (size_t)r * ldd + c * 4) = *(const f32x4*)(src + (size_t)index[r] * lds + c * 4);
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, bf16_t* __restrict__ yb,
+                                                     int ldy, int rows, int D, float eps, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? *(const f32x4*)(x + (size_t)row * ldx + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+    const float inv = scale / fmaxf(sqrtf(wave_sum(s)), eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 o = v[i] * inv;
+            if (y) *(f32x4*)(y + (size_t)row * ldy + c * 4) = o;
+            if (yb) *(uint2*)(yb + (size_t)row * ldy + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
+                                  void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd, int32_t rows,
+                                  int32_t cols, float eps, void* stream) {
+    REID_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "reid_layernorm_fwd: null pointer");
+    REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_layernorm_fwd: cols=%d unsupported", cols);
+    REID_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cols && ldy >= cols, "reid_layernorm_fwd: ld");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, row_index, gamma, beta,
+                       (bf16_t*)y_bf16, y_f32, ldy, mean, rstd, rows, cols, eps);
+    REID_CHECK_LAUNCH("reid_layernorm_fwd");
+    return REID_OK;
+}
+
+extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
+                                  const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
+                                  const float* dres, float* dx, void* dx_bf16, int32_t lddx, float* dgamma, float* dbeta,
+                                  int32_t rows, int32_t cols, void* stream) {
+    REID_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "reid_layernorm_bwd: null pointer");
+    REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_layernorm_bwd: cols=%d unsupported", cols);
+    REID_CHECK_ARG(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "reid_layernorm_bwd: ld");
+    dim3 g((rows + 3) / 4), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dy_dtype == REID_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx,
+                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx,
+                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols);
+    REID_CHECK_LAUNCH("reid_layernorm_bwd");
+    return REID_OK;
+}
+
+extern "C" int reid_patch_im2col(const float* images, void* patches, int32_t n_img, int32_t H, int32_t W, int32_t patch,
+                                 int32_t cin, void* stream) {
+    REID_CHECK_ARG(images && patches && n_img > 0, "reid_patch_im2col: null/empty");
+    REID_CHECK_ARG((cin == 1 || cin == 3) && patch % 8 == 0 && H % patch == 0 && W % patch == 0 && W % 4 == 0,
+                   "reid_patch_im2col: unsupported geometry H=%d W=%d patch=%d cin=%d", H, W, patch, cin);
+    const long total = (long)n_img * (H / patch) * (W / patch) * (cin * patch * patch / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, (bf16_t*)patches, n_img, H, W, patch, cin);
+    REID_CHECK_LAUNCH("reid_patch_im2col");
+    return REID_OK;
+}
+
+extern "C" int reid_cls_rows(const float* cls, const float* pos0, float* x, int32_t ldx, int32_t n_img, int32_t tokens,
+                             int32_t cols, void* stream) {
+    REID_CHECK_ARG(cls && pos0 && x && n_img > 0 && cols % 4 == 0 && ldx % 4 == 0, "reid_cls_rows: bad args");
+    const int n = n_img * (cols / 4);
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos0, x, ldx, n_img, tokens, cols);
+    REID_CHECK_LAUNCH("reid_cls_rows");
+    return REID_OK;
+}
+
+extern "C" int reid_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    REID_CHECK_ARG(src && dst && n > 0, "reid_cast_f32_bf16: bad args");
+    REID_CHECK_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "reid_cast_f32_bf16: pointers must be 16-byte aligned");
+    const long blocks = ((n >> 3) + 255) / 256;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks))), dim3(256), 0,
+                       (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    REID_CHECK_LAUNCH("reid_cast_f32_bf16");
+    return REID_OK;
+}
+
+extern "C" int reid_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+    REID_CHECK_ARG(src && dst && n > 0, "reid_cast_bf16_f32: bad args");
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, dst, (long)n);
+    REID_CHECK_LAUNCH("reid_cast_bf16_f32");
+    return REID_OK;
+}
+
+extern "C" int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd, int32_t rows,
+                                    int32_t cols, void* stream) {
+    REID_CHECK_ARG(src && index && dst && rows > 0 && cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "reid_gather_rows_f32: bad args");
+    const long n = (long)rows * (cols / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds, index, dst, ldd, rows, cols);
+    REID_CHECK_LAUNCH("reid_gather_rows_f32");
+    return REID_OK;
+}
+
+extern "C" int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t D,
+                                float eps, float scale, void* stream) {
+    REID_CHECK_ARG(x && (y || y_bf16) && rows > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "reid_l2norm_rows: bad args");
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, (bf16_t*)y_bf16, ldy, rows, D, eps, scale);
+    REID_CHECK_LAUNCH("reid_l2norm_rows");
+    return REID_OK;
+}

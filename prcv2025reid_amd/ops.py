@@ -1,0 +1,199 @@
+"""Thin, allocation-explicit Python wrappers over the C ABI (one function per entry point).
+
+Every wrapper takes torch CUDA tensors only as device memory + stream handles; all
+arithmetic happens inside libreid_hip.so.  Nothing here has a CPU path.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32, GemmArgs, check, lib, ptr, stream_ptr
+
+ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'quick_gelu': L.ACT_QUICK_GELU, 'relu': L.ACT_RELU,
+       'dgelu': L.ACT_DGELU, 'dquick_gelu': L.ACT_DQUICK_GELU, 'drelu': L.ACT_DRELU}
+
+
+def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None, r_period=0, aux=None,
+         C2=None, act='none', img_mod=None, mask_r=0, mask_period=0, rows_per_img=0,
+         c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None):
+    """C_out = epilogue(A @ B.T + A2 @ B2.T + bias); see reid_mer_gemm in include/reid_hip.h."""
+    a = GemmArgs()
+    a.A, a.B, a.C = ptr(A), ptr(B), ptr(C_out)
+    a.M = A.shape[0] if M is None else M
+    a.N, a.K = B.shape[0], B.shape[1]
+    a.lda, a.ldb, a.ldc = A.stride(0), B.stride(0), C_out.stride(0)
+    a.c_dtype = L.dt(C_out)
+    if A2 is not None:
+        a.A2, a.B2 = ptr(A2), ptr(B2)
+        a.K2 = K2 or B2.shape[1]
+        a.lda2, a.ldb2 = A2.stride(0), B2.stride(0)
+        a.k2_group_n = k2_group_n
+    if bias is not None:
+        a.bias = ptr(bias)
+    if R is not None:
+        a.R = ptr(R); a.ldr = R.stride(0); a.r_dtype = L.dt(R); a.r_period = r_period
+    if aux is not None:
+        a.aux = ptr(aux); a.ldaux = aux.stride(0)
+    if C2 is not None:
+        a.C2 = ptr(C2); a.ldc2 = C2.stride(0); a.c2_dtype = L.dt(C2)
+    a.act = ACT[act]
+    if mask_r:
+        a.img_mod = ptr(img_mod); a.mask_r = mask_r; a.mask_period = mask_period; a.rows_per_img = rows_per_img
+    a.c_group, a.c_group_stride, a.c_row_off = c_group, c_group_stride, c_row_off
+    a.alpha = alpha
+    check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))
+    return C_out
+
+
+def gemm_tn(X, Y, C_out, alpha=1.0, beta=0.0, M=None):
+    """C_out[P,Q] = beta*C_out + alpha * X[:M].T @ Y[:M]  (fp32 out, bf16 in)."""
+    M = X.shape[0] if M is None else M
+    check(lib().reid_gemm_tn(ptr(X), ptr(Y), ptr(C_out), M, X.shape[1], Y.shape[1], X.stride(0), Y.stride(0),
+                             C_out.stride(0), C.c_float(alpha), C.c_float(beta), stream_ptr()))
+    return C_out
+
+
+def layernorm_fwd(x, gamma, beta, y_bf16=None, y_f32=None, mean=None, rstd=None, row_index=None, rows=None,
+                  eps=1e-5):
+    rows = (row_index.shape[0] if row_index is not None else x.shape[0]) if rows is None else rows
+    y = y_bf16 if y_bf16 is not None else y_f32
+    check(lib().reid_layernorm_fwd(ptr(x), x.stride(0), ptr(row_index), ptr(gamma), ptr(beta), ptr(y_bf16), ptr(y_f32),
+                                   y.stride(0), ptr(mean), ptr(rstd), rows, x.shape[1], C.c_float(eps), stream_ptr()))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=None, dres=None, row_index=None, dgamma=None, dbeta=None,
+                  rows=None):
+    rows = (row_index.shape[0] if row_index is not None else x.shape[0]) if rows is None else rows
+    check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
+                                   ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
+                                   ptr(dbeta), rows, x.shape[1], stream_ptr()))
+
+
+def patch_im2col(images, patches, patch, cin):
+    n, _, H, W = images.shape
+    check(lib().reid_patch_im2col(ptr(images), ptr(patches), n, H, W, patch, cin, stream_ptr()))
+
+
+def cls_rows(cls, pos0, x, n_img, tokens):
+    check(lib().reid_cls_rows(ptr(cls), ptr(pos0), ptr(x), x.stride(0), n_img, tokens, x.shape[1], stream_ptr()))
+
+
+def attn_fwd(qkv, out, lse, n_seq, S, heads, causal=False, key_mask=None):
+    check(lib().reid_attn_fwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), out.stride(0), ptr(lse), n_seq, S, heads,
+                              int(causal), stream_ptr()))
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, n_seq, S, heads, causal=False, key_mask=None):
+    check(lib().reid_attn_bwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), ptr(dout), out.stride(0), ptr(lse),
+                              ptr(dqkv), dqkv.stride(0), ptr(delta_ws), n_seq, S, heads, int(causal), stream_ptr()))
+
+
+def cast_f32_bf16(src, dst):
+    check(lib().reid_cast_f32_bf16(ptr(src), ptr(dst), C.c_int64(src.numel()), stream_ptr()))
+    return dst
+
+
+def cast_bf16_f32(src, dst):
+    check(lib().reid_cast_bf16_f32(ptr(src), ptr(dst), C.c_int64(src.numel()), stream_ptr()))
+    return dst
+
+
+def to_bf16(src: torch.Tensor) -> torch.Tensor:
+    """New bf16 tensor with the values of fp32 ``src`` (round-to-nearest-even, HIP kernel)."""
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    if src.numel():
+        cast_f32_bf16(src, dst)
+    return dst
+
+
+def gather_rows(src, index, dst):
+    check(lib().reid_gather_rows_f32(ptr(src), src.stride(0), ptr(index), ptr(dst), dst.stride(0), index.shape[0],
+                                     src.shape[1], stream_ptr()))
+    return dst
+
+
+def l2norm_rows(x, y=None, y_bf16=None, eps=1e-12, scale=1.0):
+    o = y if y is not None else y_bf16
+    check(lib().reid_l2norm_rows(ptr(x), x.stride(0), ptr(y), ptr(y_bf16), o.stride(0), x.shape[0], x.shape[1],
+                                 C.c_float(eps), C.c_float(scale), stream_ptr()))
+
+
+def sgemm(A, B, C_out, *, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, act='none'):
+    """fp32 C = act(alpha * op(A) @ op(B) + bias) + beta*C on the vector ALU (small head GEMMs, exact fp32)."""
+    M = A.shape[1] if ta else A.shape[0]
+    K = A.shape[0] if ta else A.shape[1]
+    N = B.shape[0] if tb else B.shape[1]
+    sam, sak = (1, A.stride(0)) if ta else (A.stride(0), 1)
+    sbk, sbn = (1, B.stride(0)) if tb else (B.stride(0), 1)
+    check(lib().reid_sgemm(ptr(A), ptr(B), ptr(C_out), M, N, K, C.c_int64(sam), C.c_int64(sak), C.c_int64(sbk),
+                           C.c_int64(sbn), C_out.stride(0),
+                           C.c_float(alpha), C.c_float(beta), ptr(bias), ACT[act], stream_ptr()))
+    return C_out
+
+
+# ----------------------------------------------------------------------------------------- head
+def bnneck_stats(x, sum_, sqsum):
+    check(lib().reid_bnneck_stats(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(sum_), ptr(sqsum), stream_ptr()))
+
+
+def bnneck_fwd(x, gamma, beta, running_mean, running_var, sum_, sqsum, count, training, y, y_bf16, mean, invstd, rnorm,
+               eps=1e-5, momentum=0.1, scale=8.0):
+    check(lib().reid_bnneck_fwd(ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(sum_),
+                                ptr(sqsum), C.c_float(count), int(training), ptr(y), ptr(y_bf16), y.stride(0), ptr(mean),
+                                ptr(invstd), ptr(rnorm), x.shape[0], x.shape[1], C.c_float(eps), C.c_float(momentum),
+                                C.c_float(scale), stream_ptr()))
+
+
+def bnneck_bwd_p1(dy, x, gamma, beta, mean, invstd, rnorm, dz, sum_dz, sum_dz_xhat, scale=8.0):
+    check(lib().reid_bnneck_bwd_p1(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+                                   ptr(rnorm), ptr(dz), ptr(sum_dz), ptr(sum_dz_xhat), x.shape[0], x.shape[1],
+                                   C.c_float(scale), stream_ptr()))
+
+
+def bnneck_bwd_p2(dz, x, gamma, mean, invstd, sum_dz, sum_dz_xhat, count, training, dx):
+    check(lib().reid_bnneck_bwd_p2(ptr(dz), ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(invstd), ptr(sum_dz),
+                                   ptr(sum_dz_xhat), C.c_float(count), int(training), ptr(dx), dx.stride(0), x.shape[0],
+                                   x.shape[1], stream_ptr()))
+
+
+def ce_ls_fwd(logits, labels, valid, row_loss, loss_sum, smoothing=0.1):
+    check(lib().reid_ce_ls_fwd(ptr(logits), logits.stride(0), ptr(labels), ptr(valid), logits.shape[0], logits.shape[1],
+                               C.c_float(smoothing), ptr(row_loss), ptr(loss_sum), stream_ptr()))
+
+
+def ce_ls_bwd(logits, labels, valid, grad_scale, dlogits, smoothing=0.1):
+    check(lib().reid_ce_ls_bwd(ptr(logits), logits.stride(0), ptr(labels), ptr(valid), logits.shape[0], logits.shape[1],
+                               C.c_float(smoothing), ptr(grad_scale), ptr(dlogits), dlogits.stride(0), stream_ptr()))
+
+
+def sdm_ws_floats(N, Mg):
+    return int(lib().reid_sdm_ws_floats(N, Mg))
+
+
+def sdm_fwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, result):
+    check(lib().reid_sdm_fwd(ptr(q), q.stride(0), ptr(g), g.stride(0), ptr(q_label), ptr(g_label), ptr(q_valid), ptr(g_valid),
+                             q.shape[0], g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(result), stream_ptr()))
+
+
+def sdm_bwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, gscale, dq, dg):
+    check(lib().reid_sdm_bwd(ptr(q), q.stride(0), ptr(g), g.stride(0), ptr(q_label), ptr(g_label), ptr(q_valid), ptr(g_valid),
+                             q.shape[0], g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(gscale), ptr(dq), dq.stride(0),
+                             ptr(dg), dg.stride(0), stream_ptr()))
+
+
+# ----------------------------------------------------------------------------------------- retrieval
+def topk_ws_bytes(Nq, Ng, k):
+    return int(lib().reid_topk_ws_bytes(Nq, Ng, k))
+
+
+def cosine_topk(Qb, Gb, Qf, Gf, k, ws, out_idx, out_score, exclude_q=None, exclude_g=None):
+    check(lib().reid_cosine_topk(ptr(Qb), ptr(Gb), ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k,
+                                 ptr(exclude_q), ptr(exclude_g), ptr(ws), ptr(out_idx), ptr(out_score), stream_ptr()))
+
+
+def cosine_topk_exact(Qf, Gf, k, scratch, out_idx, out_score, exclude_q=None, exclude_g=None):
+    check(lib().reid_cosine_topk_exact(ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k, ptr(exclude_q),
+                                       ptr(exclude_g), ptr(scratch), ptr(out_idx), ptr(out_score), stream_ptr()))
