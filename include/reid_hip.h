@@ -146,6 +146,10 @@ int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mask, const vo
  * ------------------------------------------------------------------------------------------ */
 int reid_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int reid_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* Batched fp32 -> bf16 repack of many small matrices that live in one fp32 arena (the LoRA parameters):
+ * table[e] = {src_off, rows, cols, dst_off, dstT_off} (int64, element offsets; a negative dst offset skips that copy).
+ * dst gets the same-layout bf16 copy at dst_off and the TRANSPOSED bf16 copy at dstT_off.  One launch per step. */
+int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table, int32_t n_entries, void* stream);
 /* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */
 int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd,
                          int32_t rows, int32_t cols, void* stream);

@@ -328,3 +328,28 @@ extern "C" int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_b
     REID_CHECK_LAUNCH("reid_l2norm_rows");
     return REID_OK;
 }
+
+// ---------------------------------------------------------------- LoRA arena repack (one launch per optimizer step)
+// table[e] = {src_off, rows, cols, dst_off, dstT_off}: dst[dst_off + i] = bf16(src[src_off + i]) (same layout) and,
+// when dstT_off >= 0, dstT[dstT_off + c*rows + r] = bf16(src[src_off + r*cols + c]) (transposed copy).
+namespace {
+__global__ void pack_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const int64_t* __restrict__ table, int n) {
+    const int e = blockIdx.y;
+    if (e >= n) return;
+    const int64_t* t = table + (size_t)e * 5;
+    const int64_t so = t[0], rows = t[1], cols = t[2], d0 = t[3], dT = t[4];
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16_t v = f32_to_bf16(src[so + i]);
+        if (d0 >= 0) dst[d0 + i] = v;
+        if (dT >= 0) { const int64_t r = i / cols, c = i % cols; dst[dT + c * rows + r] = v; }
+    }
+}
+}  // namespace
+
+extern "C" int reid_pack_bf16_table(const float* src, void* dst, const int64_t* table, int32_t n_entries, void* stream) {
+    REID_CHECK_ARG(src && dst && table && n_entries > 0, "reid_pack_bf16_table: bad args");
+    hipLaunchKernelGGL(pack_table_kernel, dim3(32, n_entries), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, table, n_entries);
+    REID_CHECK_LAUNCH("reid_pack_bf16_table");
+    return REID_OK;
+}

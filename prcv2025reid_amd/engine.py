@@ -1,0 +1,364 @@
+"""Explicit forward/backward executor of the two encoders on libreid_hip.so.
+
+Vision (reference: CLIPUnifiedEncoder.encode_vision clip_backbone.py:254-286, MERTransformerBlock
+:61-85, MERLinear mer_lora.py:80-99, MERMultiheadAttention :141-231, MERMLP :267-280, PatchEmbed
+patch_embeds.py:45-76).  MI355X-first differences from the reference's execution (same arithmetic):
+
+* ALL vision modalities of a batch go through the 12 blocks in ONE pass: valid images are packed
+  [n_img, 197, 768]; the per-modality LoRA adapters are applied inside the shared GEMM as a K
+  extension: T = mask_modality(h . Acat^T) * (alpha/r) is a skinny GEMM whose epilogue zeroes the
+  columns of other modalities, then  out = h.W^T + T.Bcat^T + b  is ONE MFMA GEMM (K = 768 + Rp).
+  4x fewer, 4x larger launches than the reference's one-encoder-pass-per-modality loop.
+* q|k|v are one [768 -> 2304] GEMM; LayerNorm-1 is computed once (the reference evaluates it 3x).
+* residual stream fp32, MFMA operands bf16, fp32 accumulate; GELU / residual / bias fused in epilogues.
+* backward is hand-written: dX GEMMs reuse the same kernel with transposed packs, LoRA gradients are
+  reduce-over-rows GEMMs written straight into one flat fp32 gradient arena (one RCCL bucket).
+
+Text (reference: encode_text clip_backbone.py:288-313 -> HF CLIPTextModel): same kernels, causal +
+key-padding attention, quick_gelu, EOS pooling; forward only (the tower carries no LoRA and is frozen
+by train.py:1418-1425).
+"""
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+LIN = ('qkv', 'out', 'fc1', 'fc2')
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class LoraLayout:
+    """Where each (layer, linear) adapter set lives in the flat fp32 arena and in the bf16 pack arena."""
+
+    def __init__(self, arch):
+        self.vmods = [m for m in arch['modalities'] if m != 'text']
+        self.nmod = len(self.vmods)
+        self.r = arch['lora_rank']
+        self.Rp = round_up(self.nmod * self.r, 32)
+        self.d = arch['vision_hidden_dim']; self.ff = arch['vision_mlp_dim']
+        self.L = arch['vision_layers']
+        d, ff, Rp = self.d, self.ff, self.Rp
+        self.dims = {'qkv': (3, d, 3 * d), 'out': (1, d, d), 'fc1': (1, d, ff), 'fc2': (1, ff, d)}   # G, K(in), N(out)
+        off = 0; poff = 0
+        self.ent = {}
+        for l in range(self.L):
+            for nm in LIN:
+                G, K, N = self.dims[nm]
+                e = dict(G=G, K=K, N=N)
+                e['A'] = (off, (G * Rp, K)); off += G * Rp * K
+                e['B'] = (off, (N, Rp)); off += N * Rp
+                # bf16 packs: A, A^T, B, B^T
+                e['pA'] = poff; poff += G * Rp * K
+                e['pAT'] = poff; poff += G * Rp * K
+                e['pB'] = poff; poff += N * Rp
+                e['pBT'] = poff; poff += N * Rp
+                self.ent[(l, nm)] = e
+        self.size = off
+        self.pack_size = poff
+
+    def table(self) -> torch.Tensor:
+        rows = []
+        for (l, nm), e in self.ent.items():
+            (oa, (ra, ca)), (ob, (rb, cb)) = e['A'], e['B']
+            rows.append([oa, ra, ca, e['pA'], e['pAT']])
+            rows.append([ob, rb, cb, e['pB'], e['pBT']])
+        return torch.tensor(rows, dtype=torch.int64)
+
+    # reference key <-> arena slice ------------------------------------------------------------
+    def ref_slices(self, l: int, ref_lin: str, modality: str):
+        """(arena offset/shape info) of lora_A [r, K] and lora_B [N, r] of one reference adapter."""
+        nm, g = {'attn.q_proj': ('qkv', 0), 'attn.k_proj': ('qkv', 1), 'attn.v_proj': ('qkv', 2),
+                 'attn.out_proj': ('out', 0), 'mlp.fc1': ('fc1', 0), 'mlp.fc2': ('fc2', 0)}[ref_lin]
+        e = self.ent[(l, nm)]
+        mu = self.vmods.index(modality)
+        n_out = e['N'] // e['G']
+        return e, g, mu, n_out
+
+    def view_A(self, arena, l, nm):
+        o, shp = self.ent[(l, nm)]['A']
+        return arena[o:o + shp[0] * shp[1]].view(shp)
+
+    def view_B(self, arena, l, nm):
+        o, shp = self.ent[(l, nm)]['B']
+        return arena[o:o + shp[0] * shp[1]].view(shp)
+
+    def pk(self, pack, l, nm, which):
+        e = self.ent[(l, nm)]
+        G, K, N, Rp = e['G'], e['K'], e['N'], self.Rp
+        if which == 'A':
+            return pack[e['pA']:e['pA'] + G * Rp * K].view(G * Rp, K)
+        if which == 'AT':
+            return pack[e['pAT']:e['pAT'] + G * Rp * K].view(K, G * Rp)
+        if which == 'B':
+            return pack[e['pB']:e['pB'] + N * Rp].view(N, Rp)
+        return pack[e['pBT']:e['pBT'] + N * Rp].view(Rp, N)
+
+
+class Engine:
+    """Owns packed bf16 weights and runs the encoders.  ``P`` maps reference names -> fp32 tensors."""
+
+    def __init__(self, arch: dict, P: Dict[str, torch.Tensor], lora_arena: torch.Tensor, device):
+        self.arch = arch
+        self.P = P
+        self.lora_arena = lora_arena
+        self.dev = device
+        self.lay = LoraLayout(arch)
+        self.S = (arch['image_size'] // arch['patch_size']) ** 2 + 1
+        self.scaling = arch['lora_alpha'] / arch['lora_rank']
+        self._dense_ver = None
+        self._lora_ver = None
+        self._lora_pack = None
+        self._table = None
+        self.W = {}
+
+    # ------------------------------------------------------------------------------- packing
+    def _bf(self, t):
+        return ops.to_bf16(t.detach())
+
+    def _bft(self, t):
+        return ops.to_bf16(t.detach().t().contiguous())
+
+    def pack_dense(self):
+        P, a, W = self.P, self.arch, {}
+        ce = 'clip_encoder.'
+        for l in range(a['vision_layers']):
+            lp = f'{ce}vision_layers.{l}.'
+            wq = torch.cat([P[lp + f'attn.{n}_proj.shared_linear.weight'].detach() for n in 'qkv'], 0)
+            W[('v', l, 'qkv')] = self._bf(wq); W[('v', l, 'qkvT')] = self._bft(wq)
+            W[('v', l, 'bqkv')] = torch.cat([P[lp + f'attn.{n}_proj.shared_linear.bias'].detach() for n in 'qkv'], 0).contiguous()
+            for nm, ref in (('out', 'attn.out_proj'), ('fc1', 'mlp.fc1'), ('fc2', 'mlp.fc2')):
+                w = P[lp + ref + '.shared_linear.weight']
+                W[('v', l, nm)] = self._bf(w); W[('v', l, nm + 'T')] = self._bft(w)
+        for m in self.lay.vmods:
+            w = P[f'{ce}patch_embeds.{m}.proj.weight']
+            W[('pe', m)] = self._bf(w.reshape(w.shape[0], -1))
+        w = P[ce + 'vision_proj.weight']
+        W['vproj'] = self._bf(w); W['vprojT'] = self._bft(w)
+        tp = ce + 'clip_model.text_model.'
+        for l in range(a['text_layers']):
+            lp = f'{tp}encoder.layers.{l}.'
+            wq = torch.cat([P[lp + f'self_attn.{n}_proj.weight'].detach() for n in 'qkv'], 0)
+            W[('t', l, 'qkv')] = self._bf(wq)
+            W[('t', l, 'bqkv')] = torch.cat([P[lp + f'self_attn.{n}_proj.bias'].detach() for n in 'qkv'], 0).contiguous()
+            W[('t', l, 'out')] = self._bf(P[lp + 'self_attn.out_proj.weight'])
+            W[('t', l, 'fc1')] = self._bf(P[lp + 'mlp.fc1.weight'])
+            W[('t', l, 'fc2')] = self._bf(P[lp + 'mlp.fc2.weight'])
+        W['tproj'] = self._bf(P[ce + 'text_proj.weight'])
+        self.W = W
+
+    def pack_lora(self):
+        if self._lora_pack is None:
+            self._lora_pack = torch.empty(self.lay.pack_size, dtype=torch.bfloat16, device=self.dev)
+            self._table = self.lay.table().to(self.dev)
+        ops.pack_bf16_table(self.lora_arena.detach(), self._lora_pack, self._table, self._table.shape[0])
+
+    def refresh(self):
+        dv = sum(p._version for k, p in self.P.items() if k.startswith('clip_encoder.') and p is not self.lora_arena)
+        if dv != self._dense_ver:
+            self.pack_dense(); self._dense_ver = dv
+        lv = self.lora_arena._version
+        if lv != self._lora_ver:
+            self.pack_lora(); self._lora_ver = lv
+
+    # ------------------------------------------------------------------------------- vision forward
+    def vision_forward(self, groups: List[Tuple[int, torch.Tensor]], save: bool):
+        """groups: [(modality index, images f32 [n,3,H,W])] -> (features f32 [n_img, D], saved state)."""
+        a, P, W, lay = self.arch, self.P, self.W, self.lay
+        dev = self.dev
+        S, d, ff, Rp, r = self.S, lay.d, lay.ff, lay.Rp, lay.r
+        heads = a['vision_heads']
+        n_img = sum(g[1].shape[0] for g in groups)
+        M = n_img * S
+        ce = 'clip_encoder.'
+        mods = []
+        for mu, img in groups:
+            mods += [mu] * img.shape[0]
+        img_mod = torch.tensor(mods, dtype=torch.int32).to(dev, non_blocking=True)
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        x = torch.empty(M, d, **f32)
+        pos = P[ce + 'vision_pos_embed']
+        start = 0
+        for mu, img in groups:
+            m = lay.vmods[mu]
+            n = img.shape[0]
+            wpe = W[('pe', m)]
+            cin = wpe.shape[1] // (a['patch_size'] ** 2)
+            patches = torch.empty(n * (S - 1), wpe.shape[1], **b16)
+            ops.patch_im2col(img.contiguous(), patches, a['patch_size'], cin)
+            ops.gemm(patches, wpe, x[start * S:], bias=P[f'{ce}patch_embeds.{m}.proj.bias'], R=pos[1:], r_period=S - 1,
+                     c_group=S - 1, c_group_stride=S, c_row_off=1)
+            start += n
+        ops.cls_rows(P[ce + 'cls_token'].view(-1), pos[0], x, n_img, S)
+        mk = dict(img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=S, alpha=self.scaling)
+        pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
+        saved = []
+        buf = {}
+
+        def new(name, shape, kw):
+            if save:
+                return torch.empty(shape, **kw)
+            t = buf.get(name)
+            if t is None:
+                t = buf[name] = torch.empty(shape, **kw)
+            return t
+
+        for l in range(a['vision_layers']):
+            lp = f'{ce}vision_layers.{l}.'
+            h = new('h', (M, d), b16); mean1 = new('m1', (M,), f32); rstd1 = new('r1', (M,), f32)
+            ops.layernorm_fwd(x, P[lp + 'ln1.weight'], P[lp + 'ln1.bias'], y_bf16=h, mean=mean1, rstd=rstd1)
+            T = new('T', (M, 3 * Rp), b16)
+            ops.gemm(h, pk(l, 'qkv', 'A'), T, **mk)
+            qkv = new('qkv', (M, 3 * d), b16)
+            ops.gemm(h, W[('v', l, 'qkv')], qkv, A2=T, B2=pk(l, 'qkv', 'B'), K2=Rp, k2_group_n=d, bias=W[('v', l, 'bqkv')])
+            o = new('o', (M, d), b16); lse = new('lse', (n_img, heads, S), f32)
+            ops.attn_fwd(qkv, o, lse, n_img, S, heads)
+            To = new('To', (M, Rp), b16)
+            ops.gemm(o, pk(l, 'out', 'A'), To, **mk)
+            xm = new('xm', (M, d), f32)
+            ops.gemm(o, W[('v', l, 'out')], xm, A2=To, B2=pk(l, 'out', 'B'), K2=Rp,
+                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=x)
+            h2 = new('h2', (M, d), b16); mean2 = new('m2', (M,), f32); rstd2 = new('r2', (M,), f32)
+            ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
+            T1 = new('T1', (M, Rp), b16)
+            ops.gemm(h2, pk(l, 'fc1', 'A'), T1, **mk)
+            u = new('u', (M, ff), b16) if save else None
+            g = new('g', (M, ff), b16)
+            ops.gemm(h2, W[('v', l, 'fc1')], g, A2=T1, B2=pk(l, 'fc1', 'B'), K2=Rp,
+                     bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu', C2=u)
+            T2 = new('T2', (M, Rp), b16)
+            ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mk)
+            xn = torch.empty(M, d, **f32) if save else new('xn' + str(l & 1), (M, d), f32)
+            ops.gemm(g, W[('v', l, 'fc2')], xn, A2=T2, B2=pk(l, 'fc2', 'B'), K2=Rp,
+                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm)
+            if save:
+                saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
+                                  mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2))
+            x = xn
+        idx = (torch.arange(n_img, dtype=torch.int32) * S).to(dev, non_blocking=True)
+        cls_h = torch.empty(n_img, d, **b16); mf = torch.empty(n_img, **f32); rf = torch.empty(n_img, **f32)
+        ops.layernorm_fwd(x, P[ce + 'vision_ln_final.weight'], P[ce + 'vision_ln_final.bias'], y_bf16=cls_h, mean=mf, rstd=rf,
+                          row_index=idx)
+        feats = torch.empty(n_img, a['fusion_dim'], **f32)
+        ops.gemm(cls_h, W['vproj'], feats)
+        state = dict(layers=saved, x_final=x, idx=idx, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img) if save else None
+        return feats, state
+
+    # ------------------------------------------------------------------------------- vision backward
+    def vision_backward(self, st, dfeat: torch.Tensor) -> torch.Tensor:
+        """dfeat f32 [n_img, D] -> fp32 gradient of the LoRA arena (same layout as the arena)."""
+        a, P, W, lay = self.arch, self.P, self.W, self.lay
+        dev = self.dev
+        S, d, ff, Rp, r = self.S, lay.d, lay.ff, lay.Rp, lay.r
+        heads = a['vision_heads']
+        n_img = st['n_img']; M = n_img * S
+        ce = 'clip_encoder.'
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        grad = torch.empty(lay.size, **f32)
+        mk = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=S, alpha=self.scaling)
+        pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
+        gA = lambda l, nm: lay.view_A(grad, l, nm)
+        gB = lambda l, nm: lay.view_B(grad, l, nm)
+        dfb = ops.to_bf16(dfeat)
+        dcls = torch.empty(n_img, d, **b16)
+        ops.gemm(dfb, W['vprojT'], dcls)
+        dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
+        ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
+                          row_index=st['idx'])
+        # reusable scratch
+        U = torch.empty(M, Rp, **b16); Uq = torch.empty(M, 3 * Rp, **b16)
+        du = torch.empty(M, ff, **b16); dh = torch.empty(M, d, **b16); do = torch.empty(M, d, **b16)
+        dqkv = torch.empty(M, 3 * d, **b16); delta = torch.empty(n_img, heads, S, **f32)
+        dxm = torch.empty(M, d, **f32); dxmb = torch.empty(M, d, **b16)
+        for l in reversed(range(a['vision_layers'])):
+            s = st['layers'][l]
+            lp = f'{ce}vision_layers.{l}.'
+            # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
+            ops.gemm(dxb, pk(l, 'fc2', 'BT'), U, **mk)
+            ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
+            ops.gemm_tn(dxb, s['T2'], gB(l, 'fc2'))
+            ops.gemm_tn(U, s['g'], gA(l, 'fc2'))
+            # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
+            ops.gemm(du, pk(l, 'fc1', 'BT'), U, **mk)
+            ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U, B2=pk(l, 'fc1', 'AT'), K2=Rp)
+            ops.gemm_tn(du, s['T1'], gB(l, 'fc1'))
+            ops.gemm_tn(U, s['h2'], gA(l, 'fc1'))
+            # ---- LN2
+            ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx)
+            # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
+            ops.gemm(dxmb, pk(l, 'out', 'BT'), U, **mk)
+            ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=U, B2=pk(l, 'out', 'AT'), K2=Rp)
+            ops.gemm_tn(dxmb, s['To'], gB(l, 'out'))
+            ops.gemm_tn(U, s['o'], gA(l, 'out'))
+            # ---- attention
+            ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
+            # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
+            bT = pk(l, 'qkv', 'BT')                         # [Rp, 3d]
+            gBq = gB(l, 'qkv')                              # [3d, Rp]
+            for g in range(3):
+                ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
+                ops.gemm_tn(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d])
+            ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
+            ops.gemm_tn(Uq, s['h'], gA(l, 'qkv'))
+            # ---- LN1
+            ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm)
+        return grad
+
+    # ------------------------------------------------------------------------------- text forward
+    def text_forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        a, P, W = self.arch, self.P, self.W
+        dev = self.dev
+        tp = 'clip_encoder.clip_model.text_model.'
+        B, T = input_ids.shape
+        td, tff, heads = a['text_hidden_dim'], a['text_mlp_dim'], a['text_heads']
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        ids = input_ids.to(dev)
+        # embedding lookup is a gather (plumbing); the add is one fused epilogue-free op on [B*T, td]
+        x = (P[tp + 'embeddings.token_embedding.weight'].detach()[ids] +
+             P[tp + 'embeddings.position_embedding.weight'].detach()[:T].unsqueeze(0)).reshape(B * T, td).contiguous()
+        km = None
+        if attention_mask is not None:
+            km = attention_mask.to(dev).to(torch.uint8).contiguous()
+        M = B * T
+        h = torch.empty(M, td, **b16); qkv = torch.empty(M, 3 * td, **b16); o = torch.empty(M, td, **b16)
+        g = torch.empty(M, tff, **b16); xm = torch.empty(M, td, **f32); xn = torch.empty(M, td, **f32)
+        for l in range(a['text_layers']):
+            lp = f'{tp}encoder.layers.{l}.'
+            ops.layernorm_fwd(x, P[lp + 'layer_norm1.weight'], P[lp + 'layer_norm1.bias'], y_bf16=h)
+            ops.gemm(h, W[('t', l, 'qkv')], qkv, bias=W[('t', l, 'bqkv')])
+            ops.attn_fwd(qkv, o, None, B, T, heads, causal=True, key_mask=km)
+            ops.gemm(o, W[('t', l, 'out')], xm, bias=P[lp + 'self_attn.out_proj.bias'], R=x)
+            ops.layernorm_fwd(xm, P[lp + 'layer_norm2.weight'], P[lp + 'layer_norm2.bias'], y_bf16=h)
+            ops.gemm(h, W[('t', l, 'fc1')], g, bias=P[lp + 'mlp.fc1.bias'], act='quick_gelu')
+            ops.gemm(g, W[('t', l, 'fc2')], xn, bias=P[lp + 'mlp.fc2.bias'], R=xm)
+            x, xn = xn, x
+        eos = (ids == a['text_eos_id']).int().argmax(dim=-1)                  # first EOS (HF pooling rule)
+        idx = (torch.arange(B, device=dev) * T + eos).to(torch.int32)
+        pooled = torch.empty(B, td, **b16)
+        ops.layernorm_fwd(x, P[tp + 'final_layer_norm.weight'], P[tp + 'final_layer_norm.bias'], y_bf16=pooled, row_index=idx)
+        feats = torch.empty(B, a['fusion_dim'], **f32)
+        ops.gemm(pooled, W['tproj'], feats)
+        return feats
+
+
+class VisionEncodeFn(torch.autograd.Function):
+    """Autograd boundary of the vision executor: inputs (LoRA arena) -> per-image features."""
+
+    @staticmethod
+    def forward(ctx, engine: Engine, mods: Tuple[int, ...], lora_arena: torch.Tensor, *images):
+        need = bool(ctx.needs_input_grad[2])
+        feats, st = engine.vision_forward(list(zip(mods, images)), save=need)
+        ctx.engine = engine
+        ctx.st = st
+        ctx.n_images = len(images)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        grad = ctx.engine.vision_backward(ctx.st, dfeat.contiguous().float())
+        ctx.st = None
+        return (None, None, grad) + (None,) * ctx.n_images

@@ -1,0 +1,111 @@
+"""Autograd boundaries of the head kernels: BN-neck, classifier, label-smoothed CE, SDM loss.
+
+Reference: BNNeck.forward models/model.py:208-224; compute_loss :512-659; sdm_loss_stable
+models/sdm_loss.py:13-149.  All arithmetic is in libreid_hip.so (fp32); torch only carries the tensors.
+"""
+import torch
+
+from . import ops
+
+
+class BNNeckFn(torch.autograd.Function):
+    """y = 8 * normalize(BatchNorm1d(x)); batch statistics in training (running stats updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float):
+        x = x.contiguous().float()
+        B, D = x.shape
+        dev = x.device
+        s1 = torch.empty(D, device=dev); s2 = torch.empty(D, device=dev)
+        y = torch.empty(B, D, device=dev)
+        mean = torch.empty(D, device=dev); invstd = torch.empty(D, device=dev); rn = torch.empty(B, device=dev)
+        if training:
+            ops.bnneck_stats(x, s1, s2)
+        ops.bnneck_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, s1, s2, float(B), training, y, None, mean,
+                       invstd, rn, eps=eps, momentum=momentum, scale=8.0)
+        ctx.save_for_backward(x, gamma.detach(), beta.detach(), mean, invstd, rn)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, rn = ctx.saved_tensors
+        B, D = x.shape
+        dev = x.device
+        dy = dy.contiguous().float()
+        dz = torch.empty(B, D, device=dev); a = torch.empty(D, device=dev); b = torch.empty(D, device=dev)
+        dx = torch.empty(B, D, device=dev)
+        ops.bnneck_bwd_p1(dy, x, gamma, beta, mean, invstd, rn, dz, a, b, scale=8.0)
+        ops.bnneck_bwd_p2(dz, x, gamma, mean, invstd, a, b, float(B), ctx.training, dx)
+        return dx, b, a, None, None, None, None, None
+
+
+class LinearF32Fn(torch.autograd.Function):
+    """y = x @ W.T (+ bias) in exact fp32 (vector-ALU GEMM); used for the identity classifier."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        x = x.contiguous().float()
+        y = torch.empty(x.shape[0], W.shape[0], device=x.device)
+        ops.sgemm(x, W.detach(), y, tb=True, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(x, W.detach())
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        ops.sgemm(dy, W, dx)                                  # [B,C] @ [C,D]
+        dW = torch.empty_like(W)
+        ops.sgemm(dy, x, dW, ta=True)                         # [C,B] @ [B,D]
+        db = dy.sum(0) if ctx.has_bias else None
+        return dx, dW, db
+
+
+class CrossEntropyLSFn(torch.autograd.Function):
+    """Mean over valid rows of label-smoothed CE; returns (loss, count) with count a float tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, valid, smoothing: float):
+        logits = logits.contiguous().float()
+        acc = torch.zeros(2, device=logits.device)
+        ops.ce_ls_fwd(logits, labels, valid, None, acc, smoothing)
+        cnt = acc[1]
+        loss = acc[0] / cnt.clamp_min(1.0)
+        ctx.save_for_backward(logits, labels, valid, cnt)
+        ctx.smoothing = smoothing
+        ctx.mark_non_differentiable(cnt)
+        return loss, cnt
+
+    @staticmethod
+    def backward(ctx, dloss, _dcnt):
+        logits, labels, valid, cnt = ctx.saved_tensors
+        gs = (dloss / cnt.clamp_min(1.0)).reshape(1).float().contiguous()
+        dl = torch.empty_like(logits)
+        ops.ce_ls_bwd(logits, labels, valid, gs, dl, ctx.smoothing)
+        return dl, None, None, None
+
+
+class SDMFn(torch.autograd.Function):
+    """(loss, contributes) of sdm_loss_stable between modality features q and vis features g."""
+
+    @staticmethod
+    def forward(ctx, q, g, q_label, g_label, q_valid, g_valid, tau: float):
+        q = q.contiguous().float(); g = g.contiguous().float()
+        ws = torch.empty(ops.sdm_ws_floats(q.shape[0], g.shape[0]), device=q.device)
+        res = torch.zeros(2, device=q.device)
+        ops.sdm_fwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, res)
+        ctx.save_for_backward(q, g, q_label, g_label, q_valid, g_valid, ws)
+        ctx.tau = tau
+        loss, flag = res[0], res[1]
+        ctx.mark_non_differentiable(flag)
+        return loss, flag
+
+    @staticmethod
+    def backward(ctx, dloss, _dflag):
+        q, g, ql, gl, qv, gv, ws = ctx.saved_tensors
+        dq = torch.zeros_like(q); dg = torch.zeros_like(g)
+        ops.sdm_bwd(q, g, ql, gl, qv, gv, ctx.tau, ws, dloss.reshape(1).float().contiguous(), dq, dg)
+        return dq, dg, None, None, None, None, None

@@ -1,0 +1,454 @@
+"""Drop-in for the reference's ``models/model.py::CLIPBasedMultiModalReIDModel``.
+
+Same constructor (``config`` object read with getattr), same ``forward(images, texts, modality_masks,
+return_features)`` / ``compute_loss(outputs, labels)`` / ``set_num_classes`` / ``set_epoch`` /
+``get_learnable_params`` surface, same output-dict keys and the same ``state_dict`` key names for every
+tensor the hot path uses (reference: models/model.py:227-737).  Underneath, the
+encoders run on the HIP executor in engine.py and the BN-neck / CE / SDM kernels in head.py.  There is
+no CPU path: constructing the model needs a gfx950 device and libreid_hip.so.
+
+Deliberate differences (documented in DESIGN.md):
+  * weights are random-initialised from ``config.seed`` (prcv2025reid_amd.weights.seeded_state) unless a
+    state dict is loaded -- the reference downloads CLIP by name (clip_backbone.py:170), impossible offline;
+  * ``texts`` may be ``List[str]`` (tokenised on the host by a local tokenizer) or a dict with
+    ``input_ids``/``attention_mask`` (pre-tokenised, keeps the tokenizer off the hot path);
+  * all LoRA adapters live in ONE flat fp32 parameter (``clip_encoder.vision_layers.loras.arena``);
+    ``state_dict()`` still emits the reference's per-adapter keys, and ``load_state_dict`` accepts them;
+  * stochastic regularisers (DropPath, dropouts, batch-level modality dropout, models/model.py:435-473,
+    clip_backbone.py:126-142) are not applied; the reference's train/eval asymmetry (SDM module only in
+    train mode, models/model.py:395-399) IS kept;
+  * gradients are implemented for what the reference trains by default (train.py:1418-1425: LoRA,
+    bn_neck, null_tokens) plus the torch-side head modules; asking for gradients of frozen-by-default
+    backbone tensors raises NotImplementedError instead of silently returning none.
+"""
+import logging
+from collections import OrderedDict
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .config import arch_of
+from .engine import Engine, LoraLayout, VisionEncodeFn
+from .head import BNNeckFn, CrossEntropyLSFn, LinearF32Fn, SDMFn
+from .tokenizer import load_tokenizer
+from .weights import param_spec, seeded_tensor, is_dead_key
+
+logger = logging.getLogger(__name__)
+
+LORA_PARAM_NAME = 'clip_encoder.vision_layers.loras.arena'
+_REF_LIN = ('attn.q_proj', 'attn.k_proj', 'attn.v_proj', 'attn.out_proj', 'mlp.fc1', 'mlp.fc2')
+
+
+class LazyCount:
+    """Integer that lives on the device until someone looks at it (keeps compute_loss free of host syncs)."""
+
+    def __init__(self, t):
+        self._t = t
+
+    def __int__(self):
+        return int(self._t.item())
+
+    __index__ = __int__
+
+    def __eq__(self, o):
+        return int(self) == o
+
+    def __gt__(self, o):
+        return int(self) > o
+
+    def __repr__(self):
+        return str(int(self))
+
+
+class _NS:
+    pass
+
+
+class CLIPBasedMultiModalReIDModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.device = getattr(config, 'device', 'cuda')
+        if not torch.cuda.is_available() or not str(self.device).startswith('cuda'):
+            raise _lib.ReidHipError('CLIPBasedMultiModalReIDModel needs an MI355X (device="cuda"): the hot path has no CPU fallback')
+        _lib.check(_lib.lib().reid_check_device(torch.cuda.current_device()))
+        self.current_epoch = 0
+        self.sdm_memory = None
+        self.arch = arch_of(config)
+        self.modalities = self.arch['modalities']
+        self.vision_modalities = [m for m in self.modalities if m != 'text']
+        self.fusion_dim = self.arch['fusion_dim']
+        self.vision_hidden_dim = self.arch['vision_hidden_dim']
+        self.sdm_temperature = getattr(config, 'sdm_temperature', 0.2)
+        self.ce_weight = getattr(config, 'ce_weight', 1.0)
+        self.contrastive_weight = getattr(config, 'contrastive_weight', 0.1)
+        self.num_classes = None
+        self.bn_neck = None
+        self._ref: "OrderedDict[str, nn.Parameter]" = OrderedDict()
+        self._bufs: Dict[str, torch.Tensor] = {}
+        seed = getattr(config, 'seed', 42)
+        self._seed = seed
+        self.layout = LoraLayout(self.arch)
+        dev = torch.device(self.device)
+        lora_host = torch.zeros(self.layout.size)
+        for k, shp in param_spec(self.arch, None).items():
+            v = seeded_tensor(k, shp, seed)
+            if '.loras.' in k:
+                self._lora_put(lora_host, k, v)
+            else:
+                self._add_param(k, v.to(dev))
+        self.lora_arena = nn.Parameter(lora_host.to(dev))
+        self.register_parameter('p/' + LORA_PARAM_NAME.replace('.', '/'), self.lora_arena)
+        self._ref[LORA_PARAM_NAME] = self.lora_arena
+        self.engine = Engine(self.arch, self._ref, self.lora_arena, dev)
+        self.tokenizer = load_tokenizer(getattr(config, 'clip_model_name', ''), self.arch['text_vocab'],
+                                        self.arch['text_bos_id'], self.arch['text_eos_id'], self.arch['text_max_len'])
+        # facades so callers written against the reference's attribute paths keep working
+        self.clip_encoder = _NS()
+        self.clip_encoder.encode_vision = self.encode_vision
+        self.clip_encoder.encode_text = self.encode_text
+        self.clip_encoder.tokenizer = self.tokenizer
+        self.feature_fusion = self._fusion
+        self.sdm_module = self._sdm_module
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _add_param(self, ref_name: str, value: torch.Tensor, buffer: bool = False):
+        if buffer:
+            self._bufs[ref_name] = value
+            self.register_buffer('b/' + ref_name.replace('.', '/'), value)
+            return
+        p = nn.Parameter(value)
+        self._ref[ref_name] = p
+        self.register_parameter('p/' + ref_name.replace('.', '/'), p)
+
+    def _lora_slot(self, key: str):
+        # clip_encoder.vision_layers.{l}.{lin}.loras.{m}.lora_{A|B}.weight
+        parts = key.split('.')
+        l = int(parts[2]); lin = parts[3] + '.' + parts[4]; m = parts[6]; which = parts[7]
+        e, g, mu, n_out = self.layout.ref_slices(l, lin, m)
+        r, Rp = self.layout.r, self.layout.Rp
+        return e, g, mu, n_out, r, Rp, which
+
+    def _lora_put(self, arena: torch.Tensor, key: str, v: torch.Tensor):
+        e, g, mu, n_out, r, Rp, which = self._lora_slot(key)
+        if which == 'lora_A':
+            o, (rows, K) = e['A']
+            arena[o:o + rows * K].view(rows, K)[g * Rp + mu * r: g * Rp + (mu + 1) * r].copy_(v)
+        else:
+            o, (N, _) = e['B']
+            arena[o:o + N * Rp].view(N, Rp)[g * n_out:(g + 1) * n_out, mu * r:(mu + 1) * r].copy_(v)
+
+    def _lora_get(self, arena: torch.Tensor, key: str) -> torch.Tensor:
+        e, g, mu, n_out, r, Rp, which = self._lora_slot(key)
+        if which == 'lora_A':
+            o, (rows, K) = e['A']
+            return arena[o:o + rows * K].view(rows, K)[g * Rp + mu * r: g * Rp + (mu + 1) * r]
+        o, (N, _) = e['B']
+        return arena[o:o + N * Rp].view(N, Rp)[g * n_out:(g + 1) * n_out, mu * r:(mu + 1) * r]
+
+    def lora_grad_view(self, key: str) -> Optional[torch.Tensor]:
+        """Gradient of one reference adapter tensor (view into the arena gradient)."""
+        return None if self.lora_arena.grad is None else self._lora_get(self.lora_arena.grad, key)
+
+    def named_parameters(self, prefix: str = '', recurse: bool = True, remove_duplicate: bool = True):
+        for k, p in self._ref.items():
+            yield (prefix + ('.' if prefix else '') + k, p)
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        arena = self.lora_arena if keep_vars else self.lora_arena.detach()
+        for k in param_spec(self.arch, self.num_classes).keys():
+            if '.loras.' in k:
+                out[prefix + k] = self._lora_get(arena, k).clone()
+            elif k in self._ref:
+                out[prefix + k] = self._ref[k] if keep_vars else self._ref[k].detach()
+            elif k in self._bufs:
+                out[prefix + k] = self._bufs[k]
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        want = set(param_spec(self.arch, self.num_classes).keys())
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want and not is_dead_key(k)]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...')
+        with torch.no_grad():
+            for k, v in state_dict.items():
+                if k not in want:
+                    continue
+                v = torch.as_tensor(v)
+                if '.loras.' in k:
+                    self._lora_get(self.lora_arena, k).copy_(v.to(self.lora_arena.device))
+                elif k in self._ref:
+                    self._ref[k].copy_(v.to(self._ref[k].device))
+                else:
+                    self._bufs[k].copy_(v.to(self._bufs[k].device))
+            self.lora_arena.add_(0)          # bump versions so the bf16 packs are rebuilt
+            for p in self._ref.values():
+                p.add_(0)
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def set_num_classes(self, num_classes: int):
+        """models/model.py:310-319: create the BN-neck for ``num_classes`` identities."""
+        self.num_classes = num_classes
+        dev = torch.device(self.device)
+        for k, shp in param_spec(self.arch, num_classes).items():
+            if not k.startswith('bn_neck.'):
+                continue
+            v = seeded_tensor(k, shp, self._seed).to(dev)
+            # reference initial values: BN affine (1, 0), running (0, 1), classifier N(0, 0.001^2)
+            if k.endswith('bn.weight') or k.endswith('running_var'):
+                v = torch.ones_like(v)
+            elif k.endswith('bn.bias') or k.endswith('running_mean'):
+                v = torch.zeros_like(v)
+            elif k.endswith('classifier.weight'):
+                v = v * (0.001 / 0.02)
+            self._add_param(k, v, buffer='running_' in k)
+        self._ref['bn_neck.bn.bias'].requires_grad_(False)        # models/model.py:197
+        ns = _NS(); ns.bn = _NS(); ns.classifier = _NS()
+        ns.bn.weight = self._ref['bn_neck.bn.weight']; ns.bn.bias = self._ref['bn_neck.bn.bias']
+        ns.bn.running_mean = self._bufs['bn_neck.bn.running_mean']; ns.bn.running_var = self._bufs['bn_neck.bn.running_var']
+        ns.classifier.weight = self._ref['bn_neck.classifier.weight']
+        ns.dropout = nn.Identity()
+        self.bn_neck = ns
+        logger.info('classifier for %d identities', num_classes)
+
+    def set_epoch(self, epoch: int):
+        self.current_epoch = epoch
+
+    def _check_trainable(self):
+        for k, p in self._ref.items():
+            if p.requires_grad and k != LORA_PARAM_NAME and k.startswith('clip_encoder.'):
+                raise NotImplementedError(
+                    f'gradient of {k} requested: this build implements the reference default '
+                    '(train.py:1418-1425: only loras / bn_neck / null_tokens train; head modules via torch). '
+                    'Freeze the backbone: for n,p in model.named_parameters(): p.requires_grad = '
+                    '("loras" in n or "bn_neck" in n or "null_tokens" in n)')
+
+    # ------------------------------------------------------------------ encoders
+    def _tokens(self, texts):
+        if isinstance(texts, dict):
+            return texts['input_ids'], texts.get('attention_mask')
+        t = self.tokenizer(list(texts), return_tensors='pt', padding=True, truncation=True, max_length=self.arch['text_max_len'])
+        return t['input_ids'], t['attention_mask']
+
+    def encode_vision(self, images: torch.Tensor, modality: str) -> torch.Tensor:
+        """clip_backbone.py:254-286 for one modality."""
+        self.engine.refresh()
+        mu = self.vision_modalities.index(modality)
+        return VisionEncodeFn.apply(self.engine, (mu,), self.lora_arena, images.to(self.device).float())
+
+    def encode_text(self, texts) -> torch.Tensor:
+        """clip_backbone.py:288-313."""
+        self.engine.refresh()
+        ids, am = self._tokens(texts)
+        return self.engine.text_forward(ids, am)
+
+    # ------------------------------------------------------------------ head modules kept in torch (tiny, [B,512])
+    def _sdm_module(self, x):
+        """SemanticDisentanglementModule.forward, models/model.py:57-77 (length-1 MHA == out_proj(v_proj(x)))."""
+        P, D = self._ref, self.fusion_dim
+        wv = P['sdm_module.semantic_attn.in_proj_weight'][2 * D:]; bv = P['sdm_module.semantic_attn.in_proj_bias'][2 * D:]
+        a = F.linear(F.linear(x, wv, bv), P['sdm_module.semantic_attn.out_proj.weight'], P['sdm_module.semantic_attn.out_proj.bias'])
+        y = F.linear(x + a, P['sdm_module.semantic_proj.0.weight'], P['sdm_module.semantic_proj.0.bias'])
+        y = F.relu(F.layer_norm(y, (y.shape[-1],), P['sdm_module.semantic_proj.1.weight'], P['sdm_module.semantic_proj.1.bias']))
+        return F.linear(y, P['sdm_module.semantic_proj.4.weight'], P['sdm_module.semantic_proj.4.bias'])
+
+    def _fusion(self, features: List[torch.Tensor], masks: Optional[List[torch.Tensor]] = None):
+        """FeatureFusion.forward, models/model.py:113-183."""
+        if len(features) == 0:
+            raise ValueError('No features to fuse')
+        if len(features) == 1:
+            return features[0]
+        P, D = self._ref, self.fusion_dim
+        heads = self.arch['fusion_num_heads']
+        x = torch.stack(features, dim=1)
+        B, M, _ = x.shape
+        sm = None; add = None
+        if masks is not None:
+            sm = torch.stack(masks, dim=1).to(x.device)
+            pad = ~sm.bool()
+            dead = pad.all(dim=1)
+            # all-masked rows: unmask slot 0 and put the mean of the live rows there (model.py:141-149), sync-free
+            live = (~dead).float().view(B, 1, 1)
+            denom = (live.sum() * M).clamp_min(1.0)
+            gm = (x * live).sum(dim=(0, 1)) / denom
+            x = torch.cat([torch.where(dead.view(B, 1), gm.view(1, D).expand(B, D), x[:, 0]).unsqueeze(1), x[:, 1:]], dim=1)
+            pad = torch.cat([(pad[:, 0] & ~dead).unsqueeze(1), pad[:, 1:]], dim=1)
+            add = torch.zeros(B, 1, 1, M, device=x.device).masked_fill(pad.view(B, 1, 1, M), float('-inf'))
+        w, b = P['feature_fusion.multihead_attn.in_proj_weight'], P['feature_fusion.multihead_attn.in_proj_bias']
+        q, k, v = F.linear(x, w, b).split(D, dim=-1)
+        hd = D // heads
+        sh = lambda t: t.view(B, M, heads, hd).transpose(1, 2)
+        s = (sh(q) @ sh(k).transpose(-1, -2)) * (hd ** -0.5)
+        if add is not None:
+            s = s + add
+        a = (torch.softmax(s, dim=-1) @ sh(v)).transpose(1, 2).reshape(B, M, D)
+        a = F.linear(a, P['feature_fusion.multihead_attn.out_proj.weight'], P['feature_fusion.multihead_attn.out_proj.bias'])
+        y = F.layer_norm(x + a, (D,), P['feature_fusion.norm1.weight'], P['feature_fusion.norm1.bias'])
+        m = F.layer_norm(y, (D,), P['feature_fusion.mlp.0.weight'], P['feature_fusion.mlp.0.bias'])
+        m = F.linear(F.gelu(F.linear(m, P['feature_fusion.mlp.1.weight'], P['feature_fusion.mlp.1.bias'])),
+                     P['feature_fusion.mlp.4.weight'], P['feature_fusion.mlp.4.bias'])
+        z = F.layer_norm(y + m, (D,), P['feature_fusion.norm2.weight'], P['feature_fusion.norm2.bias'])
+        z = torch.nan_to_num(z, nan=0.0, posinf=1e4, neginf=-1e4)
+        if sm is None:
+            return z.mean(dim=1)
+        cnt = sm.sum(dim=1, keepdim=True).float().clamp(min=1.0)
+        return (z * sm.unsqueeze(-1).float()).sum(dim=1) / cnt
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: Optional[Dict[str, torch.Tensor]] = None, texts=None,
+                modality_masks: Optional[Dict[str, torch.Tensor]] = None, return_features: bool = False,
+                gather_fn=None) -> Dict[str, Any]:
+        """models/model.py:321-510.  ``gather_fn`` (data parallel only) maps (raw features, masks) of this rank's
+        rows to the global batch before the head (prcv2025reid_amd.parallel)."""
+        dev = torch.device(self.device)
+        batch_size = None
+        if images is not None:
+            for t in images.values():
+                batch_size = t.shape[0]
+                break
+        elif texts is not None:
+            batch_size = texts['input_ids'].shape[0] if isinstance(texts, dict) else len(texts)
+        if batch_size is None:
+            raise ValueError('cannot determine batch size')
+        if torch.is_grad_enabled():
+            self._check_trainable()
+        self.engine.refresh()
+        B = batch_size
+        # one host copy of all masks (no per-modality .sum() syncs as in model.py:367)
+        host_masks = {}
+        if modality_masks is not None:
+            for m, t in modality_masks.items():
+                host_masks[m] = t.detach().to('cpu').float() if torch.is_tensor(t) else torch.as_tensor(t).float()
+        raw: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        fmask: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        groups, order = [], []
+        if images is not None:
+            for m, img in images.items():
+                if m not in self.vision_modalities:
+                    continue
+                hm = host_masks.get(m)
+                if hm is not None and float(hm.sum()) > 0:
+                    idx = hm.bool()
+                    all_on = bool(idx.all())
+                    sel = img if all_on else img[idx.to(img.device)]
+                    groups.append((self.vision_modalities.index(m), sel.to(dev).float()))
+                    order.append((m, None if all_on else idx.nonzero().flatten().to(dev), hm.to(dev)))
+                else:
+                    order.append((m, 'none', torch.zeros(B, device=dev)))
+        feats = None
+        if groups:
+            feats = VisionEncodeFn.apply(self.engine, tuple(g[0] for g in groups), self.lora_arena, *[g[1] for g in groups])
+        start = 0
+        for m, idx, mask in order:
+            null = self._ref[f'null_tokens.{m}']
+            if isinstance(idx, str):
+                full = null.expand(B, -1)
+            elif idx is None:
+                full = feats[start:start + B]; start += B
+            else:
+                n = idx.shape[0]
+                full = null.expand(B, -1).clone().index_copy(0, idx, feats[start:start + n]); start += n
+            raw[m] = full; fmask[m] = mask
+        n_text = 0 if texts is None else (texts['input_ids'].shape[0] if isinstance(texts, dict) else len(texts))
+        if texts is not None and n_text > 0:
+            ids, am = self._tokens(texts)
+            tf = self.engine.text_forward(ids, am)
+            tm = host_masks.get('text')
+            if tm is not None:
+                tmd = tm.to(dev)
+                tf = torch.where(tmd.bool().view(B, 1), tf, self._ref['null_tokens.text'].expand(B, -1))
+            else:
+                tmd = torch.ones(B, device=dev)
+            raw['text'] = tf; fmask['text'] = tmd
+        if not raw:
+            raise ValueError('at least one modality is required')
+        if gather_fn is not None:
+            raw, fmask = gather_fn(raw, fmask)
+        sem = OrderedDict((m, self._sdm_module(f) if self.training else f) for m, f in raw.items())
+        flist = list(sem.values()); mlist = [fmask[m] for m in sem]
+        fused = flist[0] if len(flist) == 1 else self._fusion(flist, mlist)
+        out = {'features': fused, 'raw_modality_features': raw, 'modality_features': sem}
+        if self.bn_neck is not None:
+            P = self._ref
+            bnf = BNNeckFn.apply(fused, P['bn_neck.bn.weight'], P['bn_neck.bn.bias'], self._bufs['bn_neck.bn.running_mean'],
+                                 self._bufs['bn_neck.bn.running_var'], self.training, 0.1, 1e-5)
+            out['bn_features'] = bnf
+            out['logits'] = LinearF32Fn.apply(bnf, P['bn_neck.classifier.weight'], None)
+        if return_features:
+            out['intermediate_features'] = {'raw_modality': raw, 'semantic_modality': sem, 'fused': fused}
+        out['feature_masks'] = fmask
+        return out
+
+    # ------------------------------------------------------------------ loss
+    def compute_loss(self, outputs: Dict[str, Any], labels: torch.Tensor) -> Dict[str, Any]:
+        """models/model.py:512-659 without host syncs: validity masks and 'no positives' cases are device flags."""
+        if 'logits' not in outputs:
+            raise ValueError('outputs lack logits: call set_num_classes first')
+        logits = outputs['logits']
+        dev = logits.device
+        labels = labels.to(dev).long()
+        fm = outputs.get('feature_masks', {})
+        Bn = labels.shape[0]
+        if fm:
+            anyv = torch.zeros(Bn, dtype=torch.bool, device=dev)
+            for t in fm.values():
+                anyv |= (t > 0)
+        else:
+            anyv = torch.ones(Bn, dtype=torch.bool, device=dev)
+        valid = anyv.to(torch.uint8).contiguous()
+        ce, cnt = CrossEntropyLSFn.apply(logits, labels, valid, 0.1)
+        zero = torch.zeros((), device=dev)
+        sdm = zero
+        use_sdm = (self.current_epoch >= self.config.sdm_weight_warmup_epochs) and (self.contrastive_weight > 0)
+        raw = outputs.get('raw_modality_features', {})
+        if use_sdm and 'vis' in raw and 'vis' in fm:
+            gv = (fm['vis'] > 0).to(torch.uint8).contiguous()
+            tot, n = zero, zero
+            for m, feat in raw.items():
+                if m == 'vis' or m not in fm:
+                    continue
+                qv = (fm[m] > 0).to(torch.uint8).contiguous()
+                L, flag = SDMFn.apply(feat, raw['vis'], labels, labels, qv, gv, float(self.sdm_temperature))
+                tot = tot + L; n = n + flag
+            sdm = tot / n.clamp_min(1.0)
+        total = self.ce_weight * ce + self.contrastive_weight * sdm
+        return {'total_loss': total, 'ce_loss': ce, 'sdm_loss': sdm, 'contrastive_loss': sdm, 'ce_valid_cnt': LazyCount(cnt)}
+
+    # ------------------------------------------------------------------ optimiser groups
+    def get_learnable_params(self) -> List[Dict[str, Any]]:
+        """models/model.py:661-729 + clip_backbone.py:342-371 (same group names and learning rates)."""
+        c = self.config
+        groups = OrderedDict((n, []) for n in ('clip_backbone', 'mer_loras', 'tokenizers', 'projections',
+                                               'classification_head', 'other_modules'))
+        for name, p in self.named_parameters():
+            if name.startswith('clip_encoder.'):
+                if 'clip_model' in name:
+                    if p.requires_grad:
+                        groups['clip_backbone'].append(p)
+                elif 'lora' in name.lower():
+                    groups['mer_loras'].append(p)
+                elif 'patch_embeds' in name:
+                    groups['tokenizers'].append(p)
+                elif 'vision_proj' in name or 'text_proj' in name:
+                    groups['projections'].append(p)
+                else:
+                    groups['tokenizers'].append(p)
+            elif name.startswith('bn_neck.classifier'):
+                groups['classification_head'].append(p)
+            else:
+                groups['other_modules'].append(p)
+        lrs = {'clip_backbone': getattr(c, 'base_learning_rate', 1e-5), 'mer_loras': getattr(c, 'mer_learning_rate', 5e-5),
+               'tokenizers': getattr(c, 'tokenizer_learning_rate', 5e-5), 'projections': getattr(c, 'fusion_learning_rate', 5e-5),
+               'classification_head': 3e-3, 'other_modules': getattr(c, 'fusion_learning_rate', 5e-5)}
+        return [{'params': ps, 'lr': lrs[n], 'name': n} for n, ps in groups.items() if ps]
+
+
+def apply_reference_freeze(model: CLIPBasedMultiModalReIDModel):
+    """train.py:1418-1425: train only names containing loras / bn_neck / null_tokens."""
+    for name, p in model.named_parameters():
+        p.requires_grad = ('loras' in name or 'feature_mixture' in name or 'bn_neck' in name or 'null_tokens' in name)

@@ -109,6 +109,10 @@ def to_bf16(src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def pack_bf16_table(src_arena, dst_arena, table, n_entries):
+    check(lib().reid_pack_bf16_table(ptr(src_arena), ptr(dst_arena), ptr(table), n_entries, stream_ptr()))
+
+
 def gather_rows(src, index, dst):
     check(lib().reid_gather_rows_f32(ptr(src), src.stride(0), ptr(index), ptr(dst), dst.stride(0), index.shape[0],
                                      src.shape[1], stream_ptr()))
