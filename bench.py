@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the training hot path over one synthetic P x K batch per GPU:
+zero_grad -> forward (4 vision modalities + text through the HIP executor) -> CE + SDM losses ->
+backward (hand-written HIP backward, LoRA/bn_neck/null-token gradients = the reference's default
+trainable set, train.py:1418-1425) -> gradient all-reduce (N > 1) -> AdamW step.
+Workload at every N: BASELINE.json configs[1] per GPU (P=16, K=4, LoRA r=8, masks all-on, ViT-B/16 + CLIP
+text random-init, 400 identities), inputs resident in HBM; weak scaling.
+
+One JSON line on stdout (rank 0).  Besides the contract keys it carries
+  roofline      -- dominant kernel (mer_gemm_kernel<128,256,2,4>, bf16 MFMA): algorithmic FLOPs of every launch in
+                   the timed region / its duration measured with HIP events on the launch stream
+  cpu_baseline  -- the CPU oracle (oracle/reid_oracle.py, kind "port") timed on this host on a bounded sample
+  retrieval     -- eval queries/s of the fused cosine top-10 on 10k x 200k x 512 (BASELINE.json configs[3])
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+FLOP_PER_INSTANCE = 292.0e9    # fwd 148.25 + bwd (frozen backbone) 143.76 GFLOP at r=8, T=77
+
+
+def log(msg):
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--P', type=int, default=16)
+    ap.add_argument('--K', type=int, default=4)
+    ap.add_argument('--rank', type=int, default=8, help='LoRA rank')
+    ap.add_argument('--mask-drop', type=float, default=0.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-retrieval', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """Oracle (fp32 CPU restatement, validated against the reference) on BASELINE config 1: P=4,K=2, r=4, one
+    SDM+CE step = forward + loss + backward, no optimizer.  1 warm-up + 3 timed."""
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd.config import TrainingConfig, arch_of
+    from prcv2025reid_amd.synthetic import synthetic_batch
+    from prcv2025reid_amd.tokenizer import HashTokenizer
+    from prcv2025reid_amd.weights import seeded_state
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))            # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(cores)
+    cfg = TrainingConfig(device='cpu', mer_lora_rank=4, contrastive_weight=0.1)
+    arch = arch_of(cfg)
+    state = seeded_state(arch, 16, 0)
+    for k, t in state.items():
+        if 'loras' in k or 'bn_neck' in k or 'null_tokens' in k:
+            if t.dtype.is_floating_point and 'running_' not in k:
+                t.requires_grad_(True)
+    batch = synthetic_batch(4, 2, arch, seed=1, num_classes=16)
+    tok = HashTokenizer()(batch['texts'])
+    times = []
+    for it in range(4):
+        log(f'cpu_baseline: oracle step {it} on {cores} threads')
+        t0 = time.perf_counter()
+        out = O.forward(state, arch, batch['images'], tok, batch['modality_mask'], True)
+        L = O.compute_loss(out, batch['person_id'], contrastive_weight=0.1, tau=0.2)
+        L['total_loss'].backward()
+        for t in state.values():
+            t.grad = None
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    t = sum(times) / len(times)
+    return {'value': 8.0 / t, 'unit': 'instances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle fp32, P=4,K=2 (8 instances), LoRA r=4, fwd+loss+bwd, 1 warm-up + 3 timed steps',
+            'seconds_per_step': t}
+
+
+def retrieval_bench(dev):
+    from prcv2025reid_amd import ops
+    Nq, Ng, D, k = 10000, 200000, 512, 10
+    g = torch.Generator(device=dev).manual_seed(2)
+    Q = torch.nn.functional.normalize(torch.randn(Nq, D, device=dev, generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device=dev, generator=g), dim=1)
+    Qb, Gb = ops.to_bf16(Q), ops.to_bf16(G)
+    ws = torch.empty(ops.topk_ws_bytes(Nq, Ng, k), device=dev, dtype=torch.uint8)
+    idx = torch.empty(Nq, k, device=dev, dtype=torch.int32); sc = torch.empty(Nq, k, device=dev)
+    for _ in range(2):
+        ops.cosine_topk(Qb, Gb, Q, G, k, ws, idx, sc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        ops.cosine_topk(Qb, Gb, Q, G, k, ws, idx, sc)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    flagged = int((idx[:, 0] == -2).sum())
+    # spot check of exactness on 64 queries against fp32 matmul + stable argsort
+    ref = torch.argsort((Q[:64] @ G.t()), dim=1, descending=True, stable=True)[:, :k]
+    exact = bool((ref == idx[:64].long()).all())
+    return {'queries_per_s': Nq / t, 'ms': t * 1e3, 'Nq': Nq, 'Ng': Ng, 'D': D, 'k': k, 'tflops': 2.0 * Nq * Ng * D / t / 1e12,
+            'overflow_flagged': flagged, 'top10_equals_fp32_argsort_on_64_queries': exact}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from prcv2025reid_amd import ops
+    from prcv2025reid_amd.config import TrainingConfig
+    from prcv2025reid_amd.model import CLIPBasedMultiModalReIDModel, apply_reference_freeze
+    from prcv2025reid_amd.parallel import DataParallel
+    from prcv2025reid_amd.synthetic import synthetic_batch
+
+    C = 400
+    cfg = TrainingConfig(device=f'cuda:{local}', mer_lora_rank=args.rank, contrastive_weight=0.1, seed=0)
+    model = CLIPBasedMultiModalReIDModel(cfg)
+    model.set_num_classes(C)
+    apply_reference_freeze(model)
+    model.set_epoch(2)
+    model.train()
+    dp = DataParallel(model)
+    P, K = args.P, args.K
+    B = P * K
+    batch = synthetic_batch(P, K, model.arch, seed=1000 + rank, mask_drop=args.mask_drop, num_classes=C, label_offset=rank * P)
+    images = {m: t.to(dev) for m, t in batch['images'].items()}
+    masks = batch['modality_mask']                      # host tensors, as the reference's collate produces them
+    tok = model.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
+    tokens = {k: v.to(dev) for k, v in tok.items()}     # pre-tokenised, resident in HBM
+    labels = batch['person_id'].to(dev)
+    params = [{'params': [p for p in g['params'] if p.requires_grad], 'lr': g['lr']} for g in model.get_learnable_params()]
+    params = [g for g in params if g['params']]
+    opt = torch.optim.AdamW(params, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = dp.forward(images=images, texts=tokens, modality_masks=masks)
+        L = dp.compute_loss(out, labels)
+        L['total_loss'].backward()
+        dp.reduce_grads()
+        opt.step()
+        return L
+
+    log(f'model built, {args.warmup} warm-up steps')
+    for _ in range(args.warmup):
+        L = step()
+    log(f'timing {args.steps} steps')
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        ops.gemm_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        L = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ops.gemm_profile_end() if not args.no_kernel_events else []
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(L['total_loss'].detach())
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        res = {
+            'metric': 'multimodal instances/sec (PxK, 5-modality) at 1/2/4/8 GPU; eval queries/sec',
+            'value': value, 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'P={P},K={K} per GPU, vis/nir/sk/cp 224x224 + text (T<=77), CLIP ViT-B/16 + text tower '
+                                   f'random-init, MER-LoRA r={args.rank}, masks {"all-on" if args.mask_drop == 0 else args.mask_drop}, '
+                                   f'{C} ids, SDM+CE, fwd+bwd+AdamW (reference default trainable set)',
+                       'P': P, 'K': K, 'global_batch': world * B, 'lora_rank': args.rank, 'parallelism': f'dp{world}'},
+            'model_tflops_per_gpu': value / world * FLOP_PER_INSTANCE / 1e12,
+            'mfma_frac_whole_step': value / world * FLOP_PER_INSTANCE / 1e12 / PEAK_BF16_TFLOPS,
+            'final_loss': loss,
+        }
+        if prof:
+            fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+            ach = fl / (ms * 1e-3) / 1e12
+            res['roofline'] = {'kernel': 'mer_gemm_kernel<128,256,2,4>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': len(prof),
+                               'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps,
+                               'flops_per_launch_avg': fl / len(prof)}
+        if world == 1 and not args.no_retrieval:
+            del opt
+            torch.cuda.empty_cache()
+            log(f'train: {value:.1f} instances/s; retrieval bench')
+            res['retrieval'] = retrieval_bench(dev)
+            log(f'retrieval: {res["retrieval"]["queries_per_s"]:.0f} q/s')
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -54,6 +54,21 @@ __device__ __forceinline__ int xcd_linear_block(int bid, int nwg) {
     return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
 }
 
+// L2-aware tile order inside one XCD's contiguous run of tiles: groups of GROUP_M row-tiles are walked across ALL
+// column-tiles before moving on, so the ~64 tiles an XCD has in flight reuse the same GROUP_M activation blocks and a
+// handful of weight panels (both stay in the 4 MiB L2); with the plain "m fastest" order every weight panel pass
+// re-streamed the whole activation matrix from the Infinity Cache (18 x 81 MB per QKV GEMM).
+__device__ __forceinline__ void tile_coords(int lin, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int gid = lin / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsize = min(tiles_m - first_m, GROUP_M);
+    const int in_g = lin - gid * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
 // acc[j][i] (+)= W[n0 + wn-slice + 16j .. , :] . X[m0 + wm-slice + 16i .. , :]^T over K (64-wide steps)
 // plus the optional low-rank pair over K2 (32-wide half steps).  MFMA rows = B-operand rows (n),
 // MFMA columns = A-operand rows (m): lane holds C[m = lane&15][n = 4*(lane>>4) + reg].

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) 
     const int wm = wave / WN, wn = wave % WN;
     // query tiles fastest: concurrently running blocks share a gallery panel in L2
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
-    const int tn = lin / p.tiles_m, tm = lin % p.tiles_m;
+    int tm, tn;
+    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = p.g_begin + tn * BN;
     f32x4 acc[C::TN][C::TM];
 #pragma unroll

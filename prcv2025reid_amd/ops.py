@@ -15,6 +15,21 @@ ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'quick_gelu': L.ACT_QUICK_GELU, '
        'dgelu': L.ACT_DGELU, 'dquick_gelu': L.ACT_DQUICK_GELU, 'drelu': L.ACT_DRELU}
 
 
+# optional per-launch timing of the dominant kernel (bench.py roofline): list of (flops, bytes, start_event, end_event)
+_gemm_profile = None
+
+
+def gemm_profile_begin():
+    global _gemm_profile
+    _gemm_profile = []
+
+
+def gemm_profile_end():
+    global _gemm_profile
+    p, _gemm_profile = _gemm_profile, None
+    return p
+
+
 def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None, r_period=0, aux=None,
          C2=None, act='none', img_mod=None, mask_r=0, mask_period=0, rows_per_img=0,
          c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None):
@@ -43,6 +58,16 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         a.img_mod = ptr(img_mod); a.mask_r = mask_r; a.mask_period = mask_period; a.rows_per_img = rows_per_img
     a.c_group, a.c_group_stride, a.c_row_off = c_group, c_group_stride, c_row_off
     a.alpha = alpha
+    if _gemm_profile is not None and a.N >= 256 and a.M >= 128 and a.k2_group_n % 256 == 0:   # the 128x256-tile kernel (dominant); skinny LoRA projections use other tiles
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))
+        e1.record()
+        kk = a.K + a.K2
+        flops = 2.0 * a.M * a.N * kk
+        nbytes = 2.0 * (a.M * kk + a.N * kk) + a.M * a.N * (2 if a.c_dtype == BF16 else 4)
+        _gemm_profile.append((flops, nbytes, e0, e1))
+        return C_out
     check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))
     return C_out
 
