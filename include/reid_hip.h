@@ -46,6 +46,9 @@ typedef enum {
 
 const char* reid_last_error(void);
 int reid_version(void);
+/* 16-bit operand format of this build: 0 = bf16 (libreid_hip.so), 1 = IEEE f16 (libreid_hip_f16.so, same sources
+ * compiled with -DREID_FLAVOR_F16).  Every `bf16` / REID_BF16 in this header means "the 16-bit format of the flavor". */
+int reid_flavor(void);
 /* Checks that device `dev` is gfx950 (MI355X).  */
 int reid_check_device(int dev);
 

@@ -6,13 +6,33 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libreid_hip.so')
+LIB_PATHS = {'bf16': os.path.join(_HERE, 'csrc', 'libreid_hip.so'), 'f16': os.path.join(_HERE, 'csrc', 'libreid_hip_f16.so')}
+LIB_PATH = LIB_PATHS['bf16']
+T16_DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16}
+_flavor = os.environ.get('REID_T16', 'bf16')
+
+
+def set_flavor(name: str):
+    """Select the 16-bit MFMA operand format for everything launched afterwards ('bf16' or 'f16')."""
+    global _flavor
+    if name not in LIB_PATHS:
+        raise ValueError(f'unknown 16-bit flavor {name!r}')
+    _flavor = name
+
+
+def flavor() -> str:
+    return _flavor
+
+
+def t16() -> torch.dtype:
+    return T16_DTYPES[_flavor]
+
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU = range(7)
 
 EXPORTS = [
-    'reid_last_error', 'reid_version', 'reid_check_device', 'reid_mer_gemm', 'reid_gemm_tn',
+    'reid_last_error', 'reid_version', 'reid_flavor', 'reid_check_device', 'reid_mer_gemm', 'reid_gemm_tn',
     'reid_layernorm_fwd', 'reid_layernorm_bwd', 'reid_patch_im2col', 'reid_cls_rows',
     'reid_attn_fwd', 'reid_attn_bwd', 'reid_cast_f32_bf16', 'reid_cast_bf16_f32', 'reid_gather_rows_f32',
     'reid_bnneck_stats', 'reid_bnneck_fwd', 'reid_bnneck_bwd_p1', 'reid_bnneck_bwd_p2',
@@ -36,7 +56,7 @@ class GemmArgs(C.Structure):
                 ('alpha', C.c_float)]
 
 
-_lib = None
+_libs = {}
 
 
 class ReidHipError(RuntimeError):
@@ -44,20 +64,24 @@ class ReidHipError(RuntimeError):
 
 
 def lib():
-    """The loaded library; raises (never falls back) when it is absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ReidHipError(f'{LIB_PATH} not found: build it with `python -m prcv2025reid_amd.build` '
+    """The loaded library of the current flavor; raises (never falls back) when it is absent."""
+    h = _libs.get(_flavor)
+    if h is None:
+        path = LIB_PATHS[_flavor]
+        if not os.path.exists(path):
+            raise ReidHipError(f'{path} not found: build it with `python -m prcv2025reid_amd.build` '
                                '(there is no CPU or PyTorch fallback for the hot path)')
-        _lib = C.CDLL(LIB_PATH)
-        _lib.reid_last_error.restype = C.c_char_p
-        missing = [n for n in EXPORTS if not hasattr(_lib, n)]
+        h = C.CDLL(path)
+        h.reid_last_error.restype = C.c_char_p
+        missing = [n for n in EXPORTS if not hasattr(h, n)]
         if missing:
-            raise ReidHipError(f'{LIB_PATH} lacks symbols {missing}: stale build, run `python -m prcv2025reid_amd.build --force`')
-        _lib.reid_sdm_ws_floats.restype = C.c_int64
-        _lib.reid_topk_ws_bytes.restype = C.c_int64
-    return _lib
+            raise ReidHipError(f'{path} lacks symbols {missing}: stale build, run `python -m prcv2025reid_amd.build --force`')
+        h.reid_sdm_ws_floats.restype = C.c_int64
+        h.reid_topk_ws_bytes.restype = C.c_int64
+        if h.reid_flavor() != (1 if _flavor == 'f16' else 0):
+            raise ReidHipError(f'{path} was built for the other 16-bit flavor')
+        _libs[_flavor] = h
+    return h
 
 
 def check(rc: int):
@@ -74,7 +98,9 @@ def ptr(t):
 
 
 def dt(t) -> int:
-    if t.dtype == torch.bfloat16:
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
+        if t.dtype != t16():
+            raise TypeError(f'{t.dtype} tensor passed to the {_flavor} flavor of libreid_hip')
         return BF16
     if t.dtype == torch.float32:
         return F32

@@ -12,7 +12,9 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-LIB = os.path.join(CSRC, 'libreid_hip.so')
+LIB = os.path.join(CSRC, 'libreid_hip.so')            # bf16 operands
+LIB_F16 = os.path.join(CSRC, 'libreid_hip_f16.so')    # IEEE f16 operands (same sources, -DREID_FLAVOR_F16)
+FLAVORS = (('bf16', LIB, []), ('f16', LIB_F16, ['-DREID_FLAVOR_F16']))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-value']
 
@@ -22,9 +24,9 @@ def sources():
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(LIB_F16)):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_F16))
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
         [os.path.join(os.path.dirname(CSRC), '..', 'include', 'reid_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
@@ -33,25 +35,26 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
-    objs = []
     procs = []
-    for src in sources():
-        obj = src[:-4] + '.o'
-        objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, pr in procs:
+    for flavor, lib, defs in FLAVORS:
+        for src in sources():
+            obj = src[:-4] + f'.{flavor}.o'
+            cmd = [HIPCC] + FLAGS + defs + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, obj, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out}')
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for flavor, lib, defs in FLAVORS:
+        objs = [src[:-4] + f'.{flavor}.o' for src in sources()]
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

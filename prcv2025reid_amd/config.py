@@ -135,6 +135,10 @@ class TrainingConfig:
     best_model_path: str = "./checkpoints/best_model.pth"
     label_smoothing: float = 0.1
 
+    # 16-bit MFMA operand format of the HIP path: 'bf16' (8 significant bits) or 'f16' (11 bits, backward pass
+    # runs loss-scaled).  None -> environment REID_T16, default 'bf16'.  See DESIGN.md "Precision".
+    compute_dtype: Optional[str] = None
+
     # ---- backbone architecture (taken from the HF checkpoint in the reference) ----
     vision_layers: int = 12
     vision_heads: int = 12

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], st[kt], 0, 0, 0);
+            st[kt] = mfma32(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], st[kt]);
     }
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     float mx = -INFINITY;
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Vs, kt * 32 + 16 * s, dt * 32, lane), pack8(st[kt], s),
-                                                                 ot[dt], 0, 0, 0);
+                ot[dt] = mfma32(col_frag(Vs, kt * 32 + 16 * s, dt * 32, lane), pack8(st[kt], s),
+                                                                 ot[dt]);
     }
     if (qi < p.S) {
         const float inv = 1.0f / l;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qt * 32, 2 * ks, lane), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Gs, qt * 32, 2 * ks, lane), vf[ks], dp, 0, 0, 0);
+            s = mfma32(row_frag(Qs, qt * 32, 2 * ks, lane), kf[ks], s);
+            dp = mfma32(row_frag(Gs, qt * 32, 2 * ks, lane), vf[ks], dp);
         }
         f32x16 pm, ds;
 #pragma unroll
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Gs, qt * 32 + 16 * s2, dt * 32, lane), pack8(pm, s2), dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Qs, qt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dkt[dt], 0, 0, 0);
+                dvt[dt] = mfma32(col_frag(Gs, qt * 32 + 16 * s2, dt * 32, lane), pack8(pm, s2), dvt[dt]);
+                dkt[dt] = mfma32(col_frag(Qs, qt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dkt[dt]);
             }
     }
     if (ki < p.S) {
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, 2 * ks, lane), gf[ks], dp, 0, 0, 0);
+            s = mfma32(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], s);
+            dp = mfma32(row_frag(Vs, kt * 32, 2 * ks, lane), gf[ks], dp);
         }
         f32x16 ds;
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
-                dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Ks, kt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dqt[dt], 0, 0, 0);
+                dqt[dt] = mfma32(col_frag(Ks, kt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dqt[dt]);
     }
     if (qi < p.S) {
         bf16_t* drow = p.dqkv + ((size_t)seq * p.S + qi) * p.lddqkv + head * 64;

@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs 
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned short bf16_t;
+typedef unsigned short bf16_t;   // 16-bit storage (bf16 or f16 by flavor)
 
 void reid_set_error(const char* fmt, ...);
 
@@ -30,13 +30,34 @@ void reid_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// ---- 16-bit operand format of this library flavor -------------------------------------------------------------
+// The library is built twice from the same sources: libreid_hip.so (bf16 operands: 8 significant bits, fp32 range,
+// no loss scaling) and libreid_hip_f16.so (-DREID_FLAVOR_F16: IEEE half operands, 11 significant bits, same MFMA
+// rate).  Everything below this line is format-agnostic: `bf16_t` / `bf16x8` are just 16-bit storage types.
+typedef _Float16 __attribute__((ext_vector_type(8))) half8_t;
+#ifdef REID_FLAVOR_F16
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+#define REID_FLAVOR_ID 1
+#define REID_T16_EPS 0.00048828125f      /* 2^-11 relative rounding error */
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
 // round-to-nearest-even, NaN preserved (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+#define REID_FLAVOR_ID 0
+#define REID_T16_EPS 0.00390625f         /* 2^-8 */
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);

@@ -208,20 +208,23 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
         tile_coords(t, p.tiles_m, p.tiles_n, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
     };
-    auto issue = [&](int q) {
-        const int ti = q / S, ks = q - ti * S;
-        int m0, n0; tile_of(ti, m0, n0);
-        char* la = smem + (q % NSTAGE) * STAGE;
+    // issue pointer (runs two steps ahead of the compute pointer); tile coordinates are recomputed only per tile
+    int i_ti = 0, i_ks = 0, i_q = 0, i_m0, i_n0;
+    tile_of(0, i_m0, i_n0);
+    auto issue_next = [&]() {
+        char* la = smem + (i_q % NSTAGE) * STAGE;
         char* lb = la + C::A_BYTES;
-        if (ks < nk) {
-            stage<BM, C::NW, false>(p.A, p.lda, m0, p.M - 1, ks << 6, la, wave, lane);
-            stage<BN, C::NW, false>(p.B, p.ldb, n0, p.N - 1, ks << 6, lb, wave, lane);
+        if (i_ks < nk) {
+            stage<BM, C::NW, false>(p.A, p.lda, i_m0, p.M - 1, i_ks << 6, la, wave, lane);
+            stage<BN, C::NW, false>(p.B, p.ldb, i_n0, p.N - 1, i_ks << 6, lb, wave, lane);
         } else {
-            const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
-            const int k2 = (ks - nk) << 5;
-            stage<BM, C::NW, true>(p.A2 + (size_t)g * p.K2, p.lda2, m0, p.M - 1, k2, la, wave, lane);
-            stage<BN, C::NW, true>(p.B2, p.ldb2, n0, p.N - 1, k2, lb, wave, lane);
+            const int g = (p.k2_group_n > 0) ? (i_n0 / p.k2_group_n) : 0;
+            const int k2 = (i_ks - nk) << 5;
+            stage<BM, C::NW, true>(p.A2 + (size_t)g * p.K2, p.lda2, i_m0, p.M - 1, k2, la, wave, lane);
+            stage<BN, C::NW, true>(p.B2, p.ldb2, i_n0, p.N - 1, k2, lb, wave, lane);
         }
+        ++i_q;
+        if (++i_ks == S) { i_ks = 0; ++i_ti; if (i_ti < n_my) tile_of(i_ti, i_m0, i_n0); }
     };
 
     f32x4 acc[C::TN][C::TM];
@@ -230,18 +233,24 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fq = lane >> 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int EPI_STORES = C::TM * (16 / (64 / (WTN / 4))) * 2;   // upper bound of store instructions of one epilogue
+    static_assert(LOADS + EPI_STORES <= 63, "vmcnt immediate range");
 
-    issue(0);
-    if (Q > 1) issue(1);
-    bool drained = false;                                   // previous step ended with an epilogue (its loads/stores count in vmcnt)
+    issue_next();
+    if (Q > 1) issue_next();
+    int after_epi = 0;                                      // steps since an epilogue whose stores may still be in flight
     int ks = 0, ti = 0;
     for (int q = 0; q < Q; ++q) {
-        if (q + 1 < Q && !drained) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // vmcnt counts loads AND stores in issue order.  Stage q must have landed; younger ops that may stay in flight:
+        // stage q+1 (LOADS) and, for two steps after an epilogue, that epilogue's stores.
+        if (q + 1 >= Q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epi > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + EPI_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        if (after_epi > 0) --after_epi;
         __builtin_amdgcn_s_barrier();                       // stage q landed everywhere; everyone is done with stage q-1
         asm volatile("" ::: "memory");
-        drained = false;
-        if (q + 2 < Q) issue(q + 2);
+        if (q + 2 < Q) issue_next();
         {
             const char* la = smem + (q % NSTAGE) * STAGE;
             const char* lb = la + C::A_BYTES;
@@ -252,28 +261,27 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
                     bf16x8 af[C::TM], wf[C::TN];
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i) {
-                        const int row = wm * (BM / WM) + i * 16 + frow;
+                        const int row = wm * WTM + i * 16 + frow;
                         af[i] = *(const bf16x8*)(la + row * 128 + (swz(row, kk * 4 + fq) << 4));
                     }
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) {
-                        const int row = wn * (BN / WN) + j * 16 + frow;
+                        const int row = wn * WTN + j * 16 + frow;
                         wf[j] = *(const bf16x8*)(lb + row * 128 + (swz(row, kk * 4 + fq) << 4));
                     }
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                         for (int i = 0; i < C::TM; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                            acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
                 }
             }
         }
         if (++ks == S) {
-            // tile finished: stage buffer q % NSTAGE is free until issue(q + NSTAGE) (after the next barrier) -> staging area
+            // tile finished: stage buffer q % NSTAGE is free until the issue after the next barrier -> staging area
             int m0, n0; tile_of(ti, m0, n0);
             __builtin_amdgcn_s_barrier();                   // every wave has finished its ds_reads of stage q
             asm volatile("" ::: "memory");
-            constexpr int WTM = BM / WM, WTN = BN / WN;
             static_assert(C::NW * 16 * (WTN * 4 + 16) <= STAGE, "epilogue staging does not fit in one stage buffer");
             store_tile<C::TM, C::TN>(p, acc, smem + (q % NSTAGE) * STAGE + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM,
                                      n0 + wn * WTN, lane);
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ks = 0; ++ti; drained = true;
+            ks = 0; ++ti; after_epi = 2;
         }
     }
 }

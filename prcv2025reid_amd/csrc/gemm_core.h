@@ -120,7 +120,7 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
                 for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                        acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
             }
         }
     };

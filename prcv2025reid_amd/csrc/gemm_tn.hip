@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
         }
         if (t + 1 < steps) lstore(cur ^ 1);
         __syncthreads();

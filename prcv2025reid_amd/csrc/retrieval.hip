@@ -19,7 +19,7 @@ namespace {
 
 using namespace gemmcore;
 
-constexpr float EPS_BF16 = 0.00390625f * 1.01f;   // 2^-8 (+1 %): |q~.g~ - q.g| for unit q, g rounded to bf16
+constexpr float EPS_BF16 = 2.0f * REID_T16_EPS * 1.01f;   // |q~.g~ - q.g| <= 2*eps16 (+1 %) for unit q, g rounded to the 16-bit format
 
 struct TopkParams {
     const bf16_t* Q; const bf16_t* G;

@@ -15,6 +15,7 @@ void reid_set_error(const char* fmt, ...) {
 }
 extern "C" const char* reid_last_error(void) { return g_err; }
 extern "C" int reid_version(void) { return 100; }
+extern "C" int reid_flavor(void) { return REID_FLAVOR_ID; }
 extern "C" int reid_check_device(int dev) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {

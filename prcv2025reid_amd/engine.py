@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 LIN = ('qkv', 'out', 'fc1', 'fc2')
 
@@ -110,6 +110,12 @@ class Engine:
         self.lay = LoraLayout(arch)
         self.S = (arch['image_size'] // arch['patch_size']) ** 2 + 1
         self.scaling = arch['lora_alpha'] / arch['lora_rank']
+        # f16 operands need the backward pass scaled into half's range (gradients of a mean loss are ~1e-6..1e-3, f16
+        # normals start at 6e-5): the incoming cotangent is scaled by a power of two chosen ON DEVICE so that its largest
+        # entry is in [256, 512) (64x head-room below 65504), and the fp32 LoRA gradients are unscaled at the end.
+        # bf16 has fp32's exponent range and needs none of this.
+        self.flavor = _lib.flavor()
+        self.loss_scaling = self.flavor == 'f16'
         self._dense_ver = None
         self._lora_ver = None
         self._lora_pack = None
@@ -153,7 +159,7 @@ class Engine:
 
     def pack_lora(self):
         if self._lora_pack is None:
-            self._lora_pack = torch.empty(self.lay.pack_size, dtype=torch.bfloat16, device=self.dev)
+            self._lora_pack = torch.empty(self.lay.pack_size, dtype=_lib.t16(), device=self.dev)
             self._table = self.lay.table().to(self.dev)
         ops.pack_bf16_table(self.lora_arena.detach(), self._lora_pack, self._table, self._table.shape[0])
 
@@ -179,7 +185,7 @@ class Engine:
         for mu, img in groups:
             mods += [mu] * img.shape[0]
         img_mod = torch.tensor(mods, dtype=torch.int32).to(dev, non_blocking=True)
-        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
         x = torch.empty(M, d, **f32)
         pos = P[ce + 'vision_pos_embed']
         start = 0
@@ -257,12 +263,18 @@ class Engine:
         heads = a['vision_heads']
         n_img = st['n_img']; M = n_img * S
         ce = 'clip_encoder.'
-        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
         grad = torch.empty(lay.size, **f32)
         mk = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=S, alpha=self.scaling)
         pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
         gA = lambda l, nm: lay.view_A(grad, l, nm)
         gB = lambda l, nm: lay.view_B(grad, l, nm)
+        inv = 1.0
+        scale_t = None
+        if self.loss_scaling:
+            amax = dfeat.abs().amax().clamp_min(1e-30)
+            scale_t = torch.exp2(torch.floor(torch.log2(512.0 / amax))).clamp(2.0 ** -20, 2.0 ** 40)
+            dfeat = dfeat * scale_t
         dfb = ops.to_bf16(dfeat)
         dcls = torch.empty(n_img, d, **b16)
         ops.gemm(dfb, W['vprojT'], dcls)
@@ -280,20 +292,20 @@ class Engine:
             # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
             ops.gemm(dxb, pk(l, 'fc2', 'BT'), U, **mk)
             ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
-            ops.gemm_tn(dxb, s['T2'], gB(l, 'fc2'))
-            ops.gemm_tn(U, s['g'], gA(l, 'fc2'))
+            ops.gemm_tn(dxb, s['T2'], gB(l, 'fc2'), alpha=inv)
+            ops.gemm_tn(U, s['g'], gA(l, 'fc2'), alpha=inv)
             # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
             ops.gemm(du, pk(l, 'fc1', 'BT'), U, **mk)
             ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U, B2=pk(l, 'fc1', 'AT'), K2=Rp)
-            ops.gemm_tn(du, s['T1'], gB(l, 'fc1'))
-            ops.gemm_tn(U, s['h2'], gA(l, 'fc1'))
+            ops.gemm_tn(du, s['T1'], gB(l, 'fc1'), alpha=inv)
+            ops.gemm_tn(U, s['h2'], gA(l, 'fc1'), alpha=inv)
             # ---- LN2
             ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx)
             # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
             ops.gemm(dxmb, pk(l, 'out', 'BT'), U, **mk)
             ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=U, B2=pk(l, 'out', 'AT'), K2=Rp)
-            ops.gemm_tn(dxmb, s['To'], gB(l, 'out'))
-            ops.gemm_tn(U, s['o'], gA(l, 'out'))
+            ops.gemm_tn(dxmb, s['To'], gB(l, 'out'), alpha=inv)
+            ops.gemm_tn(U, s['o'], gA(l, 'out'), alpha=inv)
             # ---- attention
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
@@ -301,11 +313,13 @@ class Engine:
             gBq = gB(l, 'qkv')                              # [3d, Rp]
             for g in range(3):
                 ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
-                ops.gemm_tn(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d])
+                ops.gemm_tn(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d], alpha=inv)
             ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
-            ops.gemm_tn(Uq, s['h'], gA(l, 'qkv'))
+            ops.gemm_tn(Uq, s['h'], gA(l, 'qkv'), alpha=inv)
             # ---- LN1
             ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm)
+        if scale_t is not None:
+            grad.mul_(1.0 / scale_t)
         return grad
 
     # ------------------------------------------------------------------------------- text forward
@@ -315,7 +329,7 @@ class Engine:
         tp = 'clip_encoder.clip_model.text_model.'
         B, T = input_ids.shape
         td, tff, heads = a['text_hidden_dim'], a['text_mlp_dim'], a['text_heads']
-        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
         ids = input_ids.to(dev)
         # embedding lookup is a gather (plumbing); the add is one fused epilogue-free op on [B*T, td]
         x = (P[tp + 'embeddings.token_embedding.weight'].detach()[ids] +
@@ -359,6 +373,7 @@ class VisionEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
+        _lib.set_flavor(ctx.engine.flavor)
         grad = ctx.engine.vision_backward(ctx.st, dfeat.contiguous().float())
         ctx.st = None
         return (None, None, grad) + (None,) * ctx.n_images

@@ -74,6 +74,8 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self.device = getattr(config, 'device', 'cuda')
         if not torch.cuda.is_available() or not str(self.device).startswith('cuda'):
             raise _lib.ReidHipError('CLIPBasedMultiModalReIDModel needs an MI355X (device="cuda"): the hot path has no CPU fallback')
+        self.compute_dtype = getattr(config, 'compute_dtype', None) or _lib.flavor()
+        _lib.set_flavor(self.compute_dtype)
         _lib.check(_lib.lib().reid_check_device(torch.cuda.current_device()))
         self.current_epoch = 0
         self.sdm_memory = None
@@ -237,12 +239,14 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
 
     def encode_vision(self, images: torch.Tensor, modality: str) -> torch.Tensor:
         """clip_backbone.py:254-286 for one modality."""
+        _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         mu = self.vision_modalities.index(modality)
         return VisionEncodeFn.apply(self.engine, (mu,), self.lora_arena, images.to(self.device).float())
 
     def encode_text(self, texts) -> torch.Tensor:
         """clip_backbone.py:288-313."""
+        _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         ids, am = self._tokens(texts)
         return self.engine.text_forward(ids, am)
@@ -317,6 +321,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             raise ValueError('cannot determine batch size')
         if torch.is_grad_enabled():
             self._check_trainable()
+        _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         B = batch_size
         # one host copy of all masks (no per-modality .sum() syncs as in model.py:367)

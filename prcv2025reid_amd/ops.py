@@ -128,7 +128,7 @@ def cast_bf16_f32(src, dst):
 def to_bf16(src: torch.Tensor) -> torch.Tensor:
     """New bf16 tensor with the values of fp32 ``src`` (round-to-nearest-even, HIP kernel)."""
     src = src.contiguous()
-    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    dst = torch.empty(src.shape, dtype=L.t16(), device=src.device)
     if src.numel():
         cast_f32_bf16(src, dst)
     return dst
@@ -136,6 +136,9 @@ def to_bf16(src: torch.Tensor) -> torch.Tensor:
 
 def pack_bf16_table(src_arena, dst_arena, table, n_entries):
     check(lib().reid_pack_bf16_table(ptr(src_arena), ptr(dst_arena), ptr(table), n_entries, stream_ptr()))
+
+
+to_t16 = to_bf16
 
 
 def gather_rows(src, index, dst):

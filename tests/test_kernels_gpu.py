@@ -7,15 +7,23 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def ops():
+@pytest.fixture(scope='module', params=['bf16', 'f16'])
+def ops(request):
+    """Every kernel test runs once per build flavor (libreid_hip.so = bf16 operands, libreid_hip_f16.so = f16)."""
     from prcv2025reid_amd import ops as o, _lib
+    _lib.set_flavor(request.param)
     _lib.check(_lib.lib().reid_check_device(0))
-    return o
+    yield o
+    _lib.set_flavor('bf16')
+
+
+def T16():
+    from prcv2025reid_amd import _lib
+    return _lib.t16()
 
 
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(T16())
 
 
 def rel_err(a, b):
@@ -30,7 +38,7 @@ def test_gemm_plain(ops, M, N, K):
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
     A = bf(torch.randn(M, K, device='cuda', generator=g)); B = bf(torch.randn(N, K, device='cuda', generator=g) * 0.05)
     bias = torch.randn(N, device='cuda', generator=g)
-    Cb = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    Cb = torch.empty(M, N, device='cuda', dtype=T16())
     Cf = torch.empty(M, N, device='cuda', dtype=torch.float32)
     ops.gemm(A, B, Cf, bias=bias)
     ops.gemm(A, B, Cb, bias=bias)
@@ -71,7 +79,7 @@ def test_gemm_lora_extension(ops, r, G):
             Acat[gi * Rp + m * r: gi * Rp + (m + 1) * r] = lora_A[gi, m]
             B2[gi * 768:(gi + 1) * 768, m * r:(m + 1) * r] = lora_B[gi, m] * scaling
     Acat_b, B2_b = bf(Acat), bf(B2)
-    T = torch.empty(M, G * Rp, device='cuda', dtype=torch.bfloat16)
+    T = torch.empty(M, G * Rp, device='cuda', dtype=T16())
     ops.gemm(x, Acat_b, T, img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=S)
     out = torch.empty(M, N, device='cuda', dtype=torch.float32)
     ops.gemm(x, W, out, A2=T, B2=B2_b, K2=Rp, k2_group_n=768 if G > 1 else 0, bias=bias)
@@ -101,7 +109,7 @@ def test_gemm_epilogues(ops):
     bias = torch.randn(N, device='cuda', generator=g)
     R = torch.randn(M, N, device='cuda', generator=g)
     base = A.float() @ B.float().t() + bias
-    out = torch.empty(M, N, device='cuda'); pre = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    out = torch.empty(M, N, device='cuda'); pre = torch.empty(M, N, device='cuda', dtype=T16())
     ops.gemm(A, B, out, bias=bias, R=R)
     assert rel_err(out, base + R) < 2e-5
     ops.gemm(A, B, out, bias=bias, act='gelu', C2=pre)
@@ -151,7 +159,7 @@ def test_layernorm(ops, rows, cols):
     g = torch.Generator(device='cuda').manual_seed(rows)
     x = torch.randn(rows, cols, device='cuda', generator=g) * 2 + 0.5
     gamma = 1 + 0.1 * torch.randn(cols, device='cuda', generator=g); beta = 0.1 * torch.randn(cols, device='cuda', generator=g)
-    yb = torch.empty(rows, cols, device='cuda', dtype=torch.bfloat16); yf = torch.empty(rows, cols, device='cuda')
+    yb = torch.empty(rows, cols, device='cuda', dtype=T16()); yf = torch.empty(rows, cols, device='cuda')
     mean = torch.empty(rows, device='cuda'); rstd = torch.empty(rows, device='cuda')
     ops.layernorm_fwd(x, gamma, beta, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
@@ -159,7 +167,7 @@ def test_layernorm(ops, rows, cols):
     assert rel_err(yf, ref) < 1e-5 and rel_err(yb.float(), ref) < 1e-2
     dy = torch.randn(rows, cols, device='cuda', generator=g); dres = torch.randn(rows, cols, device='cuda', generator=g)
     ref.backward(dy)
-    dx = torch.empty_like(x); dxb = torch.empty(rows, cols, device='cuda', dtype=torch.bfloat16)
+    dx = torch.empty_like(x); dxb = torch.empty(rows, cols, device='cuda', dtype=T16())
     dgam = torch.zeros(cols, device='cuda'); dbet = torch.zeros(cols, device='cuda')
     ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=dxb, dres=dres, dgamma=dgam, dbeta=dbet)
     assert rel_err(dx, xr.grad + dres) < 2e-5
@@ -205,7 +213,7 @@ def test_attention(ops, n_seq, S, heads, causal, masked):
     if masked:
         km = (torch.rand(n_seq, S, device='cuda', generator=g) > 0.3).to(torch.uint8)
         km[:, 0] = 1
-    out = torch.empty(n_seq * S, d, device='cuda', dtype=torch.bfloat16)
+    out = torch.empty(n_seq * S, d, device='cuda', dtype=T16())
     lse = torch.empty(n_seq, heads, S, device='cuda')
     ops.attn_fwd(qkv, out, lse, n_seq, S, heads, causal=causal, key_mask=km)
     qf = qkv.float().requires_grad_(True)
@@ -214,7 +222,7 @@ def test_attention(ops, n_seq, S, heads, causal, masked):
     assert float((lse - ref_lse).abs().max()) < 1e-3
     dout = bf(torch.randn(n_seq * S, d, device='cuda', generator=g))
     ref.backward(dout.float())
-    dqkv = torch.zeros(n_seq * S, 3 * d, device='cuda', dtype=torch.bfloat16)
+    dqkv = torch.zeros(n_seq * S, 3 * d, device='cuda', dtype=T16())
     delta = torch.empty(n_seq, heads, S, device='cuda')
     ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, n_seq, S, heads, causal=causal, key_mask=km)
     for i, nm in enumerate('qkv'):
@@ -226,7 +234,7 @@ def test_patch_and_cls(ops):
     g = torch.Generator(device='cuda').manual_seed(3)
     img = torch.randn(5, 3, 224, 224, device='cuda', generator=g)
     for cin in (3, 1):
-        P = torch.empty(5 * 196, cin * 256, device='cuda', dtype=torch.bfloat16)
+        P = torch.empty(5 * 196, cin * 256, device='cuda', dtype=T16())
         ops.patch_im2col(img, P, 16, cin)
         x = img if cin == 3 else img.mean(1, keepdim=True)
         ref = x.view(5, cin, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(5 * 196, cin * 256)
@@ -241,9 +249,9 @@ def test_patch_and_cls(ops):
 def test_cast_and_l2norm(ops):
     g = torch.Generator(device='cuda').manual_seed(4)
     x = torch.randn(1000003, device='cuda', generator=g)
-    assert torch.equal(ops.to_bf16(x), x.to(torch.bfloat16))
+    assert torch.equal(ops.to_bf16(x), x.to(T16()))
     f = torch.randn(300, 512, device='cuda', generator=g)
-    y = torch.empty_like(f); yb = torch.empty(300, 512, device='cuda', dtype=torch.bfloat16)
+    y = torch.empty_like(f); yb = torch.empty(300, 512, device='cuda', dtype=T16())
     ops.l2norm_rows(f, y=y, y_bf16=yb)
     assert rel_err(y, torch.nn.functional.normalize(f, dim=1)) < 1e-6
 
@@ -275,7 +283,7 @@ def test_bnneck(ops, rows, training):
     xr = x.clone().requires_grad_(True)
     ref = torch.nn.functional.normalize(bn(xr), dim=1) * 8.0
     s1 = torch.empty(D, device='cuda'); s2 = torch.empty(D, device='cuda')
-    y = torch.empty(rows, D, device='cuda'); yb = torch.empty(rows, D, device='cuda', dtype=torch.bfloat16)
+    y = torch.empty(rows, D, device='cuda'); yb = torch.empty(rows, D, device='cuda', dtype=T16())
     mean = torch.empty(D, device='cuda'); invstd = torch.empty(D, device='cuda'); rn = torch.empty(rows, device='cuda')
     rm2, rv2 = rm.clone(), rv.clone()
     if training:
