@@ -1,0 +1,72 @@
+"""Cosine gallery retrieval on the HIP path (reference: train.py:428-501, tools/eval_mm_protocol.py:50-53,
+369-469, 595-649).
+
+``cosine_topk`` is the replacement for the reference's ``sim = q @ G.T; torch.argsort(sim, descending=True)``
+when only the first k ranks are consumed (CMC@1/5/10, the top-100 submission lists): it returns exactly the
+first k entries of the fp32 ranking under the (score desc, index asc) rule without materialising the
+[Nq, Ng] similarity matrix.  ``l2_normalize`` is ``F.normalize(x.float(), dim=1)`` (train.py:442).
+Everything runs in libreid_hip.so; there is no CPU path.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    ops.l2norm_rows(x, y=y, eps=eps)
+    return y
+
+
+class GalleryIndex:
+    """Device-resident gallery: fp32 rows (for exact re-scoring) + 16-bit copy (MFMA operand)."""
+
+    def __init__(self, gallery: torch.Tensor, normalized: bool = False, img_ids: Optional[torch.Tensor] = None):
+        g = gallery.contiguous().float()
+        self.Gf = g if normalized else l2_normalize(g)
+        self.Gb = ops.to_t16(self.Gf)
+        self.img_ids = None if img_ids is None else img_ids.to(self.Gf.device, torch.int32).contiguous()
+        self._ws = None
+
+    def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False,
+             query_img_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(indices int32 [Nq, k], scores f32 [Nq, k]); entries whose img id equals the query's are excluded
+        (same-image mask of eval_mm_protocol.py:421-422) when both id vectors are given."""
+        Qf = queries.contiguous().float()
+        if not normalized:
+            Qf = l2_normalize(Qf)
+        Qb = ops.to_t16(Qf)
+        Nq, Ng = Qf.shape[0], self.Gf.shape[0]
+        need = ops.topk_ws_bytes(Nq, Ng, k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=Qf.device)
+        idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
+        sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
+        exq = exg = None
+        if query_img_ids is not None and self.img_ids is not None:
+            exq = query_img_ids.to(Qf.device, torch.int32).contiguous(); exg = self.img_ids
+        ops.cosine_topk(Qb, self.Gb, Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
+        flagged = (idx[:, 0] == -2)
+        if bool(flagged.any()):        # candidate-list overflow (thousands of near-ties): exact fp32 pass for those queries
+            rows = flagged.nonzero().flatten()
+            sub_q = Qf[rows].contiguous()
+            scratch = torch.empty(sub_q.shape[0] * Ng, dtype=torch.float32, device=Qf.device)
+            sidx = torch.full((sub_q.shape[0], k), -2, dtype=torch.int32, device=Qf.device)
+            ssc = torch.empty(sub_q.shape[0], k, dtype=torch.float32, device=Qf.device)
+            ops.cosine_topk_exact(sub_q, self.Gf, k, scratch, sidx, ssc,
+                                  exclude_q=None if exq is None else exq[rows].contiguous(), exclude_g=exg)
+            idx[rows] = sidx; sc[rows] = ssc
+        return idx, sc
+
+
+def cmc_from_topk(topk_idx: torch.Tensor, q_pids: torch.Tensor, g_pids: torch.Tensor, ks=(1, 5, 10)):
+    """CMC@k over queries that have a positive in the gallery (eval_mm_protocol.py:425-441)."""
+    hit = g_pids.to(topk_idx.device)[topk_idx.long()] == q_pids.to(topk_idx.device).view(-1, 1)
+    has_pos = (q_pids.to(topk_idx.device).view(-1, 1) == g_pids.to(topk_idx.device).view(1, -1)).any(dim=1)
+    out = {}
+    for k in ks:
+        out[f'R@{k}'] = float(hit[:, :k].any(dim=1)[has_pos].float().mean()) if bool(has_pos.any()) else 0.0
+    return out

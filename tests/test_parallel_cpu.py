@@ -1,0 +1,88 @@
+"""CPU, gloo, world_size 2: the data-parallel layer (prcv2025reid_amd/parallel.py).
+
+Checks, with the CPU oracle standing in for the head, that evaluating the head on ALL-GATHERED features on every
+rank and taking rank-local rows of the gradient reproduces the single-process loss and gradients of the global
+batch (loss identical on both ranks; feature gradients = slices; encoder-side parameter gradients add up under
+all-reduce SUM)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _head_loss(raw, fmask, labels, state, arch):
+    from oracle import reid_oracle as O
+    sem = {m: O.sdm_module(f, state) for m, f in raw.items()}
+    fused = O.feature_fusion(list(sem.values()), [fmask[m] for m in sem], state, arch['fusion_num_heads'])
+    f, logits, _, _ = O.bn_neck(fused, state, True)
+    out = {'logits': logits, 'feature_masks': fmask, 'raw_modality_features': raw}
+    return O.compute_loss(out, labels, contrastive_weight=0.1, tau=0.2)['total_loss']
+
+
+def _make(seed, B):
+    g = torch.Generator().manual_seed(seed)
+    mods = ('vis', 'nir', 'text')
+    W = {m: torch.randn(16, 512, generator=g) * 0.3 for m in mods}          # stand-in "encoder": feat = x @ W_m
+    X = {m: torch.randn(B, 16, generator=g) for m in mods}
+    fmask = {'vis': torch.ones(B), 'nir': (torch.rand(B, generator=g) > 0.3).float(), 'text': torch.ones(B)}
+    labels = torch.arange(B) // 2
+    return mods, W, X, fmask, labels
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from collections import OrderedDict
+    from prcv2025reid_amd.config import TrainingConfig, arch_of
+    from prcv2025reid_amd.parallel import AllGatherRows, DataParallel, gather_no_grad
+    from prcv2025reid_amd.weights import seeded_state
+    arch = arch_of(TrainingConfig())
+    state = {k: v for k, v in seeded_state(arch, 6, 4).items() if not k.startswith('clip_encoder.')}
+    B = 8
+    mods, W, X, fmask, labels = _make(0, B)
+    b = B // world
+    sl = slice(rank * b, (rank + 1) * b)
+    Wp = {m: W[m].clone().requires_grad_(True) for m in mods}
+    raw_local = OrderedDict((m, X[m][sl] @ Wp[m]) for m in mods)
+
+    class FakeModel:                                   # just enough surface for DataParallel
+        def named_parameters(self):
+            return [(f'clip_encoder.fake.{m}', Wp[m]) for m in mods]
+    dp = DataParallel(FakeModel())
+    assert dp.world == world and dp.rank == rank
+    graw, gmask = dp._gather_fn(raw_local, OrderedDict((m, fmask[m][sl]) for m in mods))
+    glabels = gather_no_grad(labels[sl])
+    assert torch.equal(glabels, labels) and all(torch.equal(gmask[m], fmask[m]) for m in mods)
+    loss = _head_loss(graw, gmask, glabels, state, arch)
+    loss.backward()
+    dp.reduce_grads()
+    torch.save({'loss': loss.detach(), 'grads': {m: Wp[m].grad for m in mods}}, os.path.join(tmp, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_head_on_gathered_features_equals_single_process(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from prcv2025reid_amd.config import TrainingConfig, arch_of
+    from prcv2025reid_amd.weights import seeded_state
+    arch = arch_of(TrainingConfig())
+    state = {k: v for k, v in seeded_state(arch, 6, 4).items() if not k.startswith('clip_encoder.')}
+    mods, W, X, fmask, labels = _make(0, 8)
+    Wp = {m: W[m].clone().requires_grad_(True) for m in mods}
+    raw = {m: X[m] @ Wp[m] for m in mods}
+    ref = _head_loss(raw, fmask, labels, state, arch)
+    ref.backward()
+    outs = [torch.load(os.path.join(str(tmp_path), f'r{r}.pt')) for r in range(world)]
+    for o in outs:
+        assert abs(float(o['loss']) - float(ref)) < 1e-6                      # same global loss on every rank
+        for m in mods:
+            assert float((o['grads'][m] - Wp[m].grad).abs().max()) < 1e-5 * max(1.0, float(Wp[m].grad.abs().max()))
