@@ -59,6 +59,40 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ base, int ld,
     return *(const bf16x8*)(base + (size_t)row * ld + (kchunk + (lane >> 5)) * 8);
 }
 
+// Lane-constant byte offsets of the fragment reads.  Tiles start at multiples of 32 rows (and k sub-steps at multiples
+// of 16 rows), which leaves the swizzle term ((row >> 1) & 7) unchanged, so every read below is `base + tile * 4096 (+ s * 2048)
+// + lane offset`: the address arithmetic is done once per kernel instead of once per MFMA operand (the first version
+// spent 51 VALU instructions per MFMA, mostly on these addresses and on the softmax).
+struct FragOff {
+    int row[4];      // row_frag: [ks]
+    int col_lo[2];   // col_frag low 4 rows:  [dt]
+    int col_hi[2];   // col_frag high 4 rows: [dt]
+};
+__device__ __forceinline__ FragOff make_frag_off(int lane) {
+    FragOff f;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.row[ks] = r * 128 + (swz(r, 2 * ks + h) << 4);
+    const int half16 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int r_lo = 4 * h + q, r_hi = r_lo + 8;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int col = dt * 32 + 16 * half16 + 4 * pp;
+        f.col_lo[dt] = r_lo * 128 + (swz(r_lo, col >> 3) << 4) + (col & 7) * 2;
+        f.col_hi[dt] = r_hi * 128 + (swz(r_hi, col >> 3) << 4) + (col & 7) * 2;
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 row_frag_o(const char* img, int tile_row0, int ks, const FragOff& f) {
+    return *(const bf16x8*)(img + tile_row0 * 128 + f.row[ks]);
+}
+__device__ __forceinline__ bf16x8 col_frag_o(const char* img, int krow0, int dt, const FragOff& f) {
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(img + krow0 * 128 + f.col_lo[dt]));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(img + krow0 * 128 + f.col_hi[dt]));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32, x <= 0 here
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
     bf16x8 r;
 #pragma unroll
@@ -98,37 +132,51 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
     __syncthreads();
     if (q0 >= p.S) return;   // wave-uniform; no barrier follows
 
+    const FragOff fo = make_frag_off(lane);
     f32x16 st[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            st[kt] = mfma32(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], st[kt]);
+        for (int ks = 0; ks < 4; ++ks) st[kt] = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], st[kt]);
     }
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
+    const int h4 = 4 * (lane >> 5);
+    if (km || p.causal) {            // general masks (text tower, fusion): per-element predicate
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+                bool ok = key < p.S;
+                if (ok && km) ok = km[key] != 0;
+                if (p.causal) ok = ok && key <= qi;
+                st[kt][e] = ok ? st[kt][e] : -INFINITY;
+            }
+    } else {                         // vision: only the padded keys of the last tile are masked
+        constexpr int kt = NT - 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+            st[kt][e] = key < p.S ? st[kt][e] : -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + acc_row(e, lane);
-            bool ok = key < p.S;
-            if (ok && km) ok = km[key] != 0;
-            if (p.causal) ok = ok && key <= qi;
-            st[kt][e] = ok ? st[kt][e] : -INFINITY;
-            mx = fmaxf(mx, st[kt][e]);
-        }
+        for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(st[kt][e], st[kt][e + 1]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (mx == -INFINITY) mx = 0.f;
     const float c = 0.125f * LOG2E;     // head_dim^-0.5 (mer_lora.py:128-129), exp via exp2
+    const float nmc = -mx * c;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float pe = exp2f((st[kt][e] - mx) * c);
+            const float pe = fast_exp2(fmaf(st[kt][e], c, nmc));
             st[kt][e] = pe;
             l += pe;
         }
@@ -136,16 +184,17 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
 
     f32x16 ot[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                ot[dt] = mfma32(col_frag(Vs, kt * 32 + 16 * s, dt * 32, lane), pack8(st[kt], s),
-                                                                 ot[dt]);
-    }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack8(st[kt], s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(col_frag_o(Vs, kt * 32 + 16 * s2, dt, fo), pf, ot[dt]);
+        }
     if (qi < p.S) {
         const float inv = 1.0f / l;
         bf16_t* orow = p.out + ((size_t)seq * p.S + qi) * p.ldo + head * 64;
@@ -163,20 +212,26 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
 
 // ------------------------------------------------------------------------------------------ backward: delta
 // delta[seq, head, q] = sum_d dO[q, d] * O[q, d]
+// one wave per token row; a 256-element chunk (4 heads) per instruction: 8-byte loads, 16 lanes per head
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
     const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (seq*S + q)*heads + head ... one wave per (row, head)
-    const long total = (long)p.n_seq * p.S * p.heads;
-    if (item >= total) return;
-    const int head = item % p.heads;
-    const long row = item / p.heads;
-    const bf16_t* o = p.out + row * p.ldo + head * 64;
-    const bf16_t* g = p.dout + row * p.ldo + head * 64;
-    const float v = bf16_to_f32(o[lane]) * bf16_to_f32(g[lane]);
-    const float s = wave_sum(v);
-    if (lane == 0) {
-        const long seq = row / p.S, q = row % p.S;
-        p.delta[(seq * p.heads + head) * p.S + q] = s;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)p.n_seq * p.S) return;
+    const bf16_t* o = p.out + row * p.ldo;
+    const bf16_t* g = p.dout + row * p.ldo;
+    const long seq = row / p.S, q = row % p.S;
+    for (int h0 = 0; h0 < p.heads; h0 += 4) {
+        const int col = h0 * 64 + lane * 4;
+        float v = 0.f;
+        if (col < p.heads * 64) {
+            const bf16x4 a = *(const bf16x4*)(o + col), b = *(const bf16x4*)(g + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v += bf16_to_f32((bf16_t)a[e]) * bf16_to_f32((bf16_t)b[e]);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        const int head = h0 + (lane >> 4);
+        if ((lane & 15) == 0 && head < p.heads) p.delta[(seq * p.heads + head) * p.S + q] = v;
     }
 }
 
@@ -199,8 +254,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
     stage_head(gb, p.ldo, p.S, NT * 32, Gs, tid, NT * 64);
     for (int t = tid; t < NT * 32; t += NT * 64) {
         const size_t o = ((size_t)seq * p.heads + head) * p.S + t;
-        rowc[t] = t < p.S ? p.lse[o] : 0.f;
-        rowc[NT * 32 + t] = t < p.S ? p.delta[o] : 0.f;
+        rowc[t] = t < p.S ? -p.lse[o] * LOG2E : -INFINITY;          // exp2(s*c + rowc) = P; padded queries give 0
+        rowc[NT * 32 + t] = t < p.S ? -p.delta[o] * 0.125f : 0.f;
     }
     const int k0 = wave * 32;
     const int ki = k0 + (lane & 31);
@@ -216,12 +271,14 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     const bool key_ok = ki < p.S && (!km || km[ki] != 0);
 
+    const FragOff fo = make_frag_off(lane);
     f32x16 dkt[2], dvt[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
     const float c = 0.125f * LOG2E;
+    const int h4 = 4 * (lane >> 5);
     for (int qt = 0; qt < NT; ++qt) {
         if (qt * 32 >= p.S) break;
         f32x16 s, dp;
@@ -229,26 +286,40 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(row_frag(Qs, qt * 32, 2 * ks, lane), kf[ks], s);
-            dp = mfma32(row_frag(Gs, qt * 32, 2 * ks, lane), vf[ks], dp);
+            s = mfma32(row_frag_o(Qs, qt * 32, ks, fo), kf[ks], s);
+            dp = mfma32(row_frag_o(Gs, qt * 32, ks, fo), vf[ks], dp);
         }
+        // P = exp2(s*c - lse*log2e); dS = P * (dP - delta) / 8.  A lane is one key column: an invalid key only spoils its own
+        // (unused / zeroed) output column, so only the causal mask needs a per-element predicate here.
         f32x16 pm, ds;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = qt * 32 + acc_row(e, lane);
-            bool ok = key_ok && q < p.S;
-            if (p.causal) ok = ok && ki <= q;
-            const float pe = ok ? exp2f(s[e] * c - rowc[q] * LOG2E) : 0.f;
-            pm[e] = pe;
-            ds[e] = pe * (dp[e] - rowc[NT * 32 + q]) * 0.125f;
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 nl = *(const f32x4*)(rowc + qt * 32 + 8 * g + h4);
+            const f32x4 nd = *(const f32x4*)(rowc + NT * 32 + qt * 32 + 8 * g + h4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * g + j;
+                float pe = fast_exp2(fmaf(s[e], c, nl[j]));
+                if (p.causal && ki > qt * 32 + 8 * g + h4 + j) pe = 0.f;
+                pm[e] = pe;
+                ds[e] = pe * fmaf(dp[e], 0.125f, nd[j]);
+            }
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack8(pm, s2), df = pack8(ds, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvt[dt] = mfma32(col_frag_o(Gs, qt * 32 + 16 * s2, dt, fo), pf, dvt[dt]);
+                dkt[dt] = mfma32(col_frag_o(Qs, qt * 32 + 16 * s2, dt, fo), df, dkt[dt]);
+            }
+        }
+    }
+    if (!key_ok) {                                   // masked-out key: zero gradient
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dvt[dt] = mfma32(col_frag(Gs, qt * 32 + 16 * s2, dt * 32, lane), pack8(pm, s2), dvt[dt]);
-                dkt[dt] = mfma32(col_frag(Qs, qt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dkt[dt]);
-            }
+            for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
     }
     if (ki < p.S) {
         bf16_t* drow = p.dqkv + ((size_t)seq * p.S + ki) * p.lddqkv + head * 64;
@@ -289,16 +360,19 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
         gf[ks] = gfrag(gb, p.ldo, qrow, 2 * ks, lane);
     }
     const size_t so = ((size_t)seq * p.heads + head) * p.S + qrow;
-    const float lse = p.lse[so] * LOG2E, delta = p.delta[so];
+    const float nl = -p.lse[so] * LOG2E, nd = -p.delta[so] * 0.125f;
     __syncthreads();
     if (q0 >= p.S) return;
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
+    const FragOff fo = make_frag_off(lane);
     f32x16 dqt[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
     const float c = 0.125f * LOG2E;
+    const int h4 = 4 * (lane >> 5);
+    const bool slow = km != nullptr || p.causal;
     for (int kt = 0; kt < NT; ++kt) {
         if (kt * 32 >= p.S) break;
         f32x16 s, dp;
@@ -306,24 +380,29 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = mfma32(row_frag(Ks, kt * 32, 2 * ks, lane), qf[ks], s);
-            dp = mfma32(row_frag(Vs, kt * 32, 2 * ks, lane), gf[ks], dp);
+            s = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], s);
+            dp = mfma32(row_frag_o(Vs, kt * 32, ks, fo), gf[ks], dp);
         }
+        const bool edge = slow || (kt + 1) * 32 > p.S;    // only the last key tile holds padded keys
         f32x16 ds;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + acc_row(e, lane);
-            bool ok = key < p.S && qi < p.S;
-            if (ok && km) ok = km[key] != 0;
-            if (p.causal) ok = ok && key <= qi;
-            const float pe = ok ? exp2f(s[e] * c - lse) : 0.f;
-            ds[e] = pe * (dp[e] - delta) * 0.125f;
+            float pe = fast_exp2(fmaf(s[e], c, nl));
+            if (edge) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+                bool ok = key < p.S;
+                if (ok && km) ok = km[key] != 0;
+                if (p.causal) ok = ok && key <= qi;
+                pe = ok ? pe : 0.f;
+            }
+            ds[e] = pe * fmaf(dp[e], 0.125f, nd);
         }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 df = pack8(ds, s2);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                dqt[dt] = mfma32(col_frag(Ks, kt * 32 + 16 * s2, dt * 32, lane), pack8(ds, s2), dqt[dt]);
+            for (int dt = 0; dt < 2; ++dt) dqt[dt] = mfma32(col_frag_o(Ks, kt * 32 + 16 * s2, dt, fo), df, dqt[dt]);
+        }
     }
     if (qi < p.S) {
         bf16_t* drow = p.dqkv + ((size_t)seq * p.S + qi) * p.lddqkv + head * 64;
@@ -357,8 +436,8 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         attr_set = true;
     }
-    const long items = (long)p.n_seq * p.S * p.heads;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((items + 3) / 4)), dim3(256), 0, s, p);
+    const long rows = (long)p.n_seq * p.S;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(delta)");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS1, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(dkv)");

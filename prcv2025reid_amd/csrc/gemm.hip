@@ -372,8 +372,9 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
     hipStream_t s = (hipStream_t)stream;
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
-    if (a->N <= 32) return launch<256, 32, 4, 1>(p, s);
-    if (a->N <= 64) return launch<256, 64, 4, 1>(p, s);
+    // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip)
+    if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
+    if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);
     static int tile = -1;
     if (tile < 0) { const char* e = getenv("REID_GEMM_TILE"); tile = e ? atoi(e) : 0; }
