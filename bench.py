@@ -12,7 +12,7 @@ Workload at every N: BASELINE.json configs[1] per GPU (P=16, K=4, LoRA r=8, mask
 text random-init, 400 identities), inputs resident in HBM; weak scaling.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mer_gemm_kernel<128,256,2,4>, bf16 MFMA): algorithmic FLOPs of every launch in
+  roofline      -- dominant kernel (mer_gemm_kernel<256,256,2,4> + <128,256,2,4>, bf16 MFMA): algorithmic FLOPs of every launch in
                    the timed region / its duration measured with HIP events on the launch stream
   cpu_baseline  -- the CPU oracle (oracle/reid_oracle.py, kind "port") timed on this host on a bounded sample
   retrieval     -- eval queries/s of the fused cosine top-10 on 10k x 200k x 512 (BASELINE.json configs[3])
@@ -203,7 +203,7 @@ def main():
         if prof:
             fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
             ach = fl / (ms * 1e-3) / 1e12
-            res['roofline'] = {'kernel': 'mer_gemm_kernel<128,256,2,4>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+            res['roofline'] = {'kernel': 'mer_gemm_kernel<256,256,2,4> + <128,256,2,4>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': len(prof),
                                'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps,
                                'flops_per_launch_avg': fl / len(prof)}

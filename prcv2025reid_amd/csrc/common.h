@@ -74,11 +74,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact-erf GELU (nn.GELU() default, mer_lora.py:257) without libm's erff (~100 instructions with branches: it made
+// the fc1 epilogue cost as much as the fc1 GEMM).  Normal CDF by Abramowitz-Stegun 7.1.26 on erfc (|abs error| <= 1.5e-7,
+// and RELATIVE accuracy kept in the negative tail because erfc is evaluated directly, no 1 - x cancellation):
+//   erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt(2)
+// exp(-z^2) = exp(-x^2/2) is also the Gaussian density needed by the derivative.
+__device__ __forceinline__ void gauss_cdf_pdf(float x, float& cdf, float& pdf_unnorm) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2/2) = 2^(-x^2 log2(e)/2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float q = 0.5f * poly * e;                                                  // 0.5 erfc(|x|/sqrt2)
+    cdf = x >= 0.f ? 1.0f - q : q;
+    pdf_unnorm = e;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    float c, e;
+    gauss_cdf_pdf(x, c, e);
+    return x * c;
+}
 __device__ __forceinline__ float dgelu_erf_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float c, e;
+    gauss_cdf_pdf(x, c, e);
+    return fmaf(x * 0.39894228040143268f, e, c);
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float dquick_gelu_f(float x) {

@@ -30,6 +30,7 @@ struct GemmParams {
     int c_group, c_group_stride, c_row_off;
     float alpha;
     int tiles_m, tiles_n;
+    int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue
 };
 
 using namespace gemmcore;
@@ -38,43 +39,80 @@ using namespace gemmcore;
 // The accumulator layout (lane = one output row, 4 consecutive columns per 16x16 sub-tile) would store 8-byte pieces
 // scattered over 16 rows per instruction (measured: that store tail cost as much as the whole K loop at K = 768).
 // Instead the wave transposes the sub-tile through its own LDS slice `stg`, 16 output rows at a time, and then works
-// on 16-byte ROW pieces: the lanes of one instruction cover whole contiguous row segments, so bias / residual / aux
-// loads and the C stores are full-line coalesced.
-template <int TM, int TN>
-__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], char* stg, int m_base, int n_base, int lane) {
+// on ROW pieces of CW columns per lane (CW = 8 for 16-bit outputs, 4 for fp32 outputs, i.e. always 16-byte stores: the
+// store tail is issue-bound, so halving the instruction count halves it -- cdna_hip_programming.md T21): the lanes of
+// one instruction cover whole contiguous row segments, so bias / residual / aux loads and the C stores are full-line
+// coalesced.  All global operands of the epilogue are requested BEFORE the LDS transposes start.
+template <int CW>
+struct Piece { float v[CW]; };
+
+template <int CW>
+__device__ __forceinline__ void store_piece(void* base, int dtype, size_t elem_off, const float (&v)[CW]) {
+    if (dtype == REID_F32) {
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) *(f32x4*)((float*)base + elem_off + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    } else if (CW == 8) {
+        *(uint4*)((bf16_t*)base + elem_off) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    } else {
+        *(uint2*)((bf16_t*)base + elem_off) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+}
+template <int CW>
+__device__ __forceinline__ void load_piece(const void* base, int dtype, size_t elem_off, float (&v)[CW]) {
+    if (dtype == REID_F32) {
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) {
+            const f32x4 t = *(const f32x4*)((const float*)base + elem_off + 4 * q);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+    } else if (CW == 8) {
+        const bf16x8 t = *(const bf16x8*)((const bf16_t*)base + elem_off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((bf16_t)t[e]);
+    } else {
+        const bf16x4 t = *(const bf16x4*)((const bf16_t*)base + elem_off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32((bf16_t)t[e]);
+    }
+}
+
+template <int TM, int TN, int CW>
+__device__ __forceinline__ void store_tile_w(const GemmParams& p, f32x4 (&acc)[TN][TM], char* stg, int m_base, int n_base, int lane) {
     constexpr int WTN = TN * 16;
     constexpr int PITCH = WTN * 4 + 16;                 // bytes per staged row (+16: conflict-free 16-byte writes)
-    constexpr int LPR = WTN / 4;                        // lanes per staged row
+    constexpr int LPR = WTN / CW;                       // lanes per staged row
     constexpr int RPI = 64 / LPR;                       // rows per read instruction
     static_assert(64 % LPR == 0 && 16 % RPI == 0, "unsupported wave tile width");
     constexpr int IT = 16 / RPI;                        // read instructions per 16 staged rows
-    constexpr bool PREF = (TM * IT <= 16);              // prefetch residual / aux operands of the whole sub-tile
+    constexpr bool PREF = (TM * IT * CW <= 64);         // prefetch residual / aux operands of the whole sub-tile (VGPR budget)
     const int mrow = lane & 15;
     const int ncol4 = (lane >> 4) * 4;
-    const int rr = lane / LPR, rc4 = (lane % LPR) * 4;
-    const int n = n_base + rc4;                         // this lane's 4 output columns: the same for every row it handles
+    const int rr = lane / LPR, rc = (lane % LPR) * CW;
+    const int n = n_base + rc;                          // this lane's CW output columns: the same for every row it handles
     const bool nok = n < p.N;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && nok) bv = *(const f32x4*)(p.bias + n);
-    // All global operands of the epilogue are requested BEFORE the LDS transposes start: issued inside the row loop
-    // every 16-row step waited a full memory latency (measured ~8 us of fixed cost per 128x128 tile).
-    f32x4 rv[PREF ? TM : 1][PREF ? IT : 1];
-    bf16x4 av[PREF ? TM : 1][PREF ? IT : 1];
-    auto load_r = [&](int m) -> f32x4 {
-        const int rrow = p.r_period > 0 ? (m % p.r_period) : m;
-        if (p.r_dtype == REID_F32) return *(const f32x4*)((const float*)p.R + (size_t)rrow * p.ldr + n);
-        const bf16x4 q = *(const bf16x4*)((const bf16_t*)p.R + (size_t)rrow * p.ldr + n);
-        return f32x4{bf16_to_f32((bf16_t)q[0]), bf16_to_f32((bf16_t)q[1]), bf16_to_f32((bf16_t)q[2]), bf16_to_f32((bf16_t)q[3])};
+    const int nc = nok ? n : 0;                         // clamped: operand loads are unconditional (no branch, no wait between them)
+    const int mlast = p.M - 1;
+    float bv[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) bv[e] = 0.f;
+    if (p.bias) load_piece<CW>(p.bias, REID_F32, nc, bv);
+    // LoRA routing mask: which of this lane's columns belong to which modality is a per-lane constant
+    int colmod[CW];
+    if (p.mask_r > 0) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) colmod[e] = ((nc + e) % p.mask_period) / p.mask_r;
+    }
+    Piece<CW> rv[PREF ? TM : 1][PREF ? IT : 1], av[PREF ? TM : 1][PREF ? IT : 1];
+    auto r_off = [&](int m) -> size_t {
+        const int mc = m < mlast ? m : mlast;
+        return (size_t)(p.r_period > 0 ? mc % p.r_period : mc) * p.ldr + nc;
     };
     if (PREF) {
         if (p.R) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const int m = m_base + i * 16 + it * RPI + rr;
-                    rv[i][it] = (m < p.M && nok) ? load_r(m) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int it = 0; it < IT; ++it) load_piece<CW>(p.R, p.r_dtype, r_off(m_base + i * 16 + it * RPI + rr), rv[i][it].v);
         }
         if (p.act >= REID_ACT_DGELU_ERF) {
 #pragma unroll
@@ -82,7 +120,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
                     const int m = m_base + i * 16 + it * RPI + rr;
-                    av[i][it] = (m < p.M && nok) ? *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n) : bf16x4{0, 0, 0, 0};
+                    load_piece<CW>(p.aux, REID_BF16, (size_t)(m < mlast ? m : mlast) * p.ldaux + nc, av[i][it].v);
                 }
         }
     }
@@ -94,48 +132,80 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = it * RPI + rr;
-            f32x4 v = *(const f32x4*)(stg + r * PITCH + rc4 * 4);
             const int m = m_base + i * 16 + r;
-            if (m >= p.M || !nok) continue;
-            v += bv;
-            if (p.R) v += PREF ? rv[PREF ? i : 0][PREF ? it : 0] : load_r(m);
-            const size_t crow = p.c_group > 0
-                                    ? (size_t)(m / p.c_group) * p.c_group_stride + (m % p.c_group) + p.c_row_off
-                                    : (size_t)m;
-            if (p.C2) {
-                if (p.c2_dtype == REID_F32) *(f32x4*)((float*)p.C2 + crow * p.ldc2 + n) = v;
-                else *(uint2*)((bf16_t*)p.C2 + crow * p.ldc2 + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            float v[CW];
+#pragma unroll
+            for (int q = 0; q < CW / 4; ++q) {
+                const f32x4 t = *(const f32x4*)(stg + r * PITCH + (rc + 4 * q) * 4);
+                v[4 * q] = t[0] + bv[4 * q]; v[4 * q + 1] = t[1] + bv[4 * q + 1];
+                v[4 * q + 2] = t[2] + bv[4 * q + 2]; v[4 * q + 3] = t[3] + bv[4 * q + 3];
             }
-            if (p.act != REID_ACT_NONE) {
-                if (p.act <= REID_ACT_RELU) {
+            if (p.R) {
+                if (PREF) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = v[e];
-                        v[e] = p.act == REID_ACT_GELU_ERF ? gelu_erf_f(x)
-                               : p.act == REID_ACT_QUICK_GELU ? quick_gelu_f(x) : fmaxf(x, 0.f);
-                    }
+                    for (int e = 0; e < CW; ++e) v[e] += rv[PREF ? i : 0][PREF ? it : 0].v[e];
                 } else {
-                    const bf16x4 u = PREF ? av[PREF ? i : 0][PREF ? it : 0] : *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
+                    float t[CW];
+                    load_piece<CW>(p.R, p.r_dtype, r_off(m), t);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = bf16_to_f32((bf16_t)u[e]);
-                        v[e] *= p.act == REID_ACT_DGELU_ERF ? dgelu_erf_f(x)
-                                : p.act == REID_ACT_DQUICK_GELU ? dquick_gelu_f(x) : (x > 0.f ? 1.f : 0.f);
+                    for (int e = 0; e < CW; ++e) v[e] += t[e];
+                }
+            }
+            const bool ok = m < p.M && nok;
+            size_t crow = (size_t)m;
+            if (p.c_group > 0) crow = (size_t)(m / p.c_group) * p.c_group_stride + (m % p.c_group) + p.c_row_off;
+            if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, v);
+            if (p.act != REID_ACT_NONE) {
+                if (p.act == REID_ACT_GELU_ERF) {           // (uniform branches: only the selected activation is evaluated)
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (p.act == REID_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[e] = quick_gelu_f(v[e]);
+                } else if (p.act == REID_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else {
+                    float u[CW];
+                    if (PREF) {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) u[e] = av[PREF ? i : 0][PREF ? it : 0].v[e];
+                    } else {
+                        load_piece<CW>(p.aux, REID_BF16, (size_t)(m < mlast ? m : mlast) * p.ldaux + nc, u);
+                    }
+                    if (p.act == REID_ACT_DGELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[e] *= dgelu_erf_f(u[e]);
+                    } else if (p.act == REID_ACT_DQUICK_GELU) {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[e] *= dquick_gelu_f(u[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[e] *= (u[e] > 0.f ? 1.f : 0.f);
                     }
                 }
             }
             if (p.mask_r > 0) {
-                const int modality = p.img_mod[m / p.rows_per_img];
+                const int modality = p.img_mod[(m < mlast ? m : mlast) / p.rows_per_img];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (((n + e) % p.mask_period) / p.mask_r != modality) v[e] = 0.f;
+                for (int e = 0; e < CW; ++e)
+                    if (colmod[e] != modality) v[e] = 0.f;
             }
-            v *= p.alpha;
-            if (p.c_dtype == REID_F32) *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
-            else *(uint2*)((bf16_t*)p.C + crow * p.ldc + n) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+#pragma unroll
+            for (int e = 0; e < CW; ++e) v[e] *= p.alpha;
+            if (ok) store_piece<CW>(p.C, p.c_dtype, crow * p.ldc + n, v);
         }
         asm volatile("" ::: "memory");
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], char* stg, int m_base, int n_base, int lane) {
+    // 16-byte stores in both cases; N % 8 == 0 is needed for the 8-wide form
+    const bool wide = p.c_dtype != REID_F32 && ((p.N | p.ldc) & 7) == 0 && (!p.C2 || (p.ldc2 & 7) == 0) &&
+                      (!p.R || (p.ldr & 7) == 0) && (!p.aux || (p.ldaux & 7) == 0);
+    if (wide) store_tile_w<TM, TN, 8>(p, acc, stg, m_base, n_base, lane);
+    else store_tile_w<TM, TN, 4>(p, acc, stg, m_base, n_base, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -166,7 +236,7 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_kernel(const GemmParams 
     constexpr int WTM = BM / WM, WTN = BN / WN;
     static_assert(C::NW * 16 * (WTN * 4 + 16) <= C::LDS_BYTES, "epilogue staging does not fit");
     __syncthreads();                                    // all waves are done reading the operand buffers
-    store_tile<C::TM, C::TN>(p, acc, smem + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM, n0 + wn * WTN, lane);
+    if (p.dbg != 1) store_tile<C::TM, C::TN>(p, acc, smem + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -208,15 +278,22 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
         tile_coords(t, p.tiles_m, p.tiles_n, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
     };
-    // issue pointer (runs two steps ahead of the compute pointer); tile coordinates are recomputed only per tile
+    // issue pointer (runs two steps ahead of the compute pointer); tile coordinates and the per-lane load offsets are
+    // recomputed only per tile
     int i_ti = 0, i_ks = 0, i_q = 0, i_m0, i_n0;
-    tile_of(0, i_m0, i_n0);
+    uint32_t offA[C::A_INSTR], offB[C::B_INSTR];
+    auto new_tile = [&]() {
+        tile_of(i_ti, i_m0, i_n0);
+        stage_offsets<BM, C::NW, false>(p.lda, i_m0, p.M - 1, wave, lane, offA);
+        stage_offsets<BN, C::NW, false>(p.ldb, i_n0, p.N - 1, wave, lane, offB);
+    };
+    new_tile();
     auto issue_next = [&]() {
         char* la = smem + (i_q % NSTAGE) * STAGE;
         char* lb = la + C::A_BYTES;
         if (i_ks < nk) {
-            stage<BM, C::NW, false>(p.A, p.lda, i_m0, p.M - 1, i_ks << 6, la, wave, lane);
-            stage<BN, C::NW, false>(p.B, p.ldb, i_n0, p.N - 1, i_ks << 6, lb, wave, lane);
+            stage_from<BM, C::NW>((const char*)p.A + (size_t)i_ks * 128, offA, la, wave);
+            stage_from<BN, C::NW>((const char*)p.B + (size_t)i_ks * 128, offB, lb, wave);
         } else {
             const int g = (p.k2_group_n > 0) ? (i_n0 / p.k2_group_n) : 0;
             const int k2 = (i_ks - nk) << 5;
@@ -224,7 +301,7 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
             stage<BN, C::NW, true>(p.B2, p.ldb2, i_n0, p.N - 1, k2, lb, wave, lane);
         }
         ++i_q;
-        if (++i_ks == S) { i_ks = 0; ++i_ti; if (i_ti < n_my) tile_of(i_ti, i_m0, i_n0); }
+        if (++i_ks == S) { i_ks = 0; ++i_ti; if (i_ti < n_my) new_tile(); }
     };
 
     f32x4 acc[C::TN][C::TM];
@@ -283,8 +360,9 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const Gem
             __builtin_amdgcn_s_barrier();                   // every wave has finished its ds_reads of stage q
             asm volatile("" ::: "memory");
             static_assert(C::NW * 16 * (WTN * 4 + 16) <= STAGE, "epilogue staging does not fit in one stage buffer");
-            store_tile<C::TM, C::TN>(p, acc, smem + (q % NSTAGE) * STAGE + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM,
-                                     n0 + wn * WTN, lane);
+            if (p.dbg != 1)
+                store_tile<C::TM, C::TN>(p, acc, smem + (q % NSTAGE) * STAGE + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM,
+                                         n0 + wn * WTN, lane);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
@@ -345,6 +423,8 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     REID_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K && a->lda % 8 == 0 && a->ldb % 8 == 0,
                    "reid_mer_gemm: lda/ldb must be >= K and multiples of 8 (16-byte rows)");
     REID_CHECK_ARG(a->ldc >= a->N && a->ldc % 4 == 0, "reid_mer_gemm: ldc=%d", a->ldc);
+    REID_CHECK_ARG((int64_t)a->M * a->lda * 2 < (1ll << 32) && (int64_t)a->N * a->ldb * 2 < (1ll << 32),
+                   "reid_mer_gemm: operands beyond 4 GiB need 64-bit lane offsets (M*lda=%lld)", (long long)a->M * a->lda);
     if (a->A2) {
         REID_CHECK_ARG(a->B2 && a->K2 > 0 && a->K2 % 32 == 0, "reid_mer_gemm: K2=%d must be a positive multiple of 32",
                        a->K2);
@@ -376,16 +456,24 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
     if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);
-    static int tile = -1;
-    if (tile < 0) { const char* e = getenv("REID_GEMM_TILE"); tile = e ? atoi(e) : 0; }
+    // experiment knobs (read per call so a benchmark can A/B tiles inside one process)
+    const char* e_tile = getenv("REID_GEMM_TILE");
+    const char* e_dbg = getenv("REID_GEMM_DBG");
+    const int tile = e_tile ? atoi(e_tile) : 0;
+    p.dbg = e_dbg ? atoi(e_dbg) : 0;
     if (tile == 4) return launch_persist<256, 128, 4, 2, 3>(p, s);
     if (tile == 5) return launch_persist<128, 256, 2, 4, 3>(p, s);
     if (tile == 6) return launch_persist<128, 128, 2, 2, 4>(p, s);
     if (tile == 1) return launch<256, 128, 4, 2>(p, s);
     if (tile == 2) return launch<256, 256, 2, 4>(p, s);
     if (tile == 3) return launch<128, 128, 2, 2>(p, s);
-    // default: 128x256 tile, 8 waves (best of the measured variants on the ViT shapes: tools/bench_gemm.py)
-    // (a column tile must not straddle two LoRA groups of the fused q|k|v projection)
-    if (tile == 0 && a->N >= 256 && a->M >= 128 && (p.k2_group_n == 0 || p.k2_group_n % 256 == 0)) return launch<128, 256, 2, 4>(p, s);
+    if (tile == 8) return launch<128, 256, 2, 4>(p, s);
+    // defaults from same-process A/B runs of the seven ViT GEMM variants (tools/bench_gemm_variants.py):
+    //   256x256 tile where the epilogue has no per-element global operand (no residual, no saved pre-activation), else
+    //   128x256 (its epilogue prefetches residual / aux for the whole sub-tile).  A column tile must not straddle two
+    //   LoRA groups of the fused q|k|v projection.
+    const bool grp_ok = p.k2_group_n == 0 || p.k2_group_n % 256 == 0;
+    if (tile == 0 && grp_ok && a->N >= 512 && a->M >= 512 && !a->R && a->act < REID_ACT_DGELU_ERF) return launch<256, 256, 2, 4>(p, s);
+    if (tile == 0 && grp_ok && a->N >= 256 && a->M >= 128) return launch<128, 256, 2, 4>(p, s);
     return launch<128, 128, 2, 2>(p, s);
 }

@@ -47,6 +47,30 @@ __device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int ld, in
 }
 
 
+// Per-lane byte offsets of one operand tile's LDS-DMA loads (row clamp + source swizzle), computed ONCE per tile:
+// inside the K loop a load is then `uniform base (advances by 128 B per step, SALU) + 32-bit lane offset`, no vector
+// address arithmetic (the first version spent ~4 VALU instructions per MFMA, mostly on 64-bit load addresses).
+template <int ROWS, int NW, bool HALF>
+__device__ __forceinline__ void stage_offsets(int ld, int row0, int row_max, int wave, int lane, uint32_t (&off)[ROWS / 8 / NW]) {
+    constexpr int INSTR = ROWS / 8 / NW;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3);
+        int c = swz(r, lane & 7);
+        if (HALF) c &= 3;
+        int grow = row0 + r;
+        grow = grow < row_max ? grow : row_max;
+        off[i] = (uint32_t)grow * (uint32_t)ld * 2u + (uint32_t)c * 16u;
+    }
+}
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_from(const char* __restrict__ base, const uint32_t (&off)[ROWS / 8 / NW], char* lds, int wave) {
+    constexpr int INSTR = ROWS / 8 / NW;
+#pragma unroll
+    for (int i = 0; i < INSTR; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(lds + (i * NW + wave) * 8 * 128), 16, 0, 0);
+}
+
 // XCD-aware linear tile id: blocks b and b+8 share an XCD (one L2); every XCD gets a contiguous run
 // of tiles (bijective for any grid size, cdna_hip_programming.md section 5 "XCD swizzle").
 __device__ __forceinline__ int xcd_linear_block(int bid, int nwg) {
@@ -86,12 +110,15 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
     const int nk2 = A2 ? (K2 >> 5) : 0;
     const int steps = nk + nk2;
 
+    uint32_t offA[C::A_INSTR], offB[C::B_INSTR];
+    stage_offsets<BM, C::NW, false>(lda, m0, M - 1, wave, lane, offA);
+    stage_offsets<BN, C::NW, false>(ldb, n0, N - 1, wave, lane, offB);
     auto issue = [&](int t, int buf) {
         char* la = smem + buf * C::BUF_BYTES;
         char* lb = la + C::A_BYTES;
         if (t < nk) {
-            stage<BM, C::NW, false>(A, lda, m0, M - 1, t << 6, la, wave, lane);
-            stage<BN, C::NW, false>(B, ldb, n0, N - 1, t << 6, lb, wave, lane);
+            stage_from<BM, C::NW>((const char*)A + (size_t)t * 128, offA, la, wave);
+            stage_from<BN, C::NW>((const char*)B + (size_t)t * 128, offB, lb, wave);
         } else {
             const int k2 = (t - nk) << 5;
             stage<BM, C::NW, true>(A2, lda2, m0, M - 1, k2, la, wave, lane);

@@ -58,7 +58,7 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         a.img_mod = ptr(img_mod); a.mask_r = mask_r; a.mask_period = mask_period; a.rows_per_img = rows_per_img
     a.c_group, a.c_group_stride, a.c_row_off = c_group, c_group_stride, c_row_off
     a.alpha = alpha
-    if _gemm_profile is not None and a.N >= 256 and a.M >= 128 and a.k2_group_n % 256 == 0:   # the 128x256-tile kernel (dominant); skinny LoRA projections use other tiles
+    if _gemm_profile is not None and a.N >= 256 and a.M >= 128 and a.k2_group_n % 256 == 0:   # both big-tile instantiations   # the 128x256-tile kernel (dominant); skinny LoRA projections use other tiles
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))

@@ -1,0 +1,44 @@
+"""Model-shaped GEMM variants (epilogues as the engine uses them), per tile config (REID_GEMM_TILE)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from prcv2025reid_amd import ops, _lib
+T16 = _lib.t16()
+M, d, ff, Rp = 64 * 4 * 197, 768, 3072, 32
+g = torch.Generator(device='cuda').manual_seed(0)
+def rnd(*shape, scale=1.0, dt=None):
+    return (torch.randn(*shape, device='cuda', generator=g) * scale).to(dt or T16)
+def timeit(fn, reps=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+h = rnd(M, d); gact = rnd(M, ff); T = rnd(M, 3 * Rp)
+Wqkv = rnd(3 * d, d, scale=0.03); Bq = rnd(3 * d, Rp, scale=0.1); bq = rnd(3 * d, dt=torch.float32)
+Wo = rnd(d, d, scale=0.03); Bo = rnd(d, Rp, scale=0.1); bo = rnd(d, dt=torch.float32)
+W1 = rnd(ff, d, scale=0.03); B1 = rnd(ff, Rp, scale=0.1); b1 = rnd(ff, dt=torch.float32)
+W2 = rnd(d, ff, scale=0.03)
+x = rnd(M, d, dt=torch.float32); xo = torch.empty(M, d, device='cuda')
+qkv = torch.empty(M, 3 * d, device='cuda', dtype=T16); u = torch.empty(M, ff, device='cuda', dtype=T16); g2 = torch.empty(M, ff, device='cuda', dtype=T16)
+dh = torch.empty(M, d, device='cuda', dtype=T16)
+cases = [
+ ('qkv  bf16+bias+lora(g)', 2.0*M*3*d*(d+Rp), lambda: ops.gemm(h, Wqkv, qkv, A2=T, B2=Bq, K2=Rp, k2_group_n=d, bias=bq)),
+ ('out  f32+bias+R(f32)  ', 2.0*M*d*(d+Rp), lambda: ops.gemm(h, Wo, xo, A2=T[:, :Rp], B2=Bo, K2=Rp, bias=bo, R=x)),
+ ('fc1  bf16+gelu+C2     ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, bias=b1, act='gelu', C2=u)),
+ ('fc2  f32+bias+R K=3072', 2.0*M*d*(ff+Rp), lambda: ops.gemm(gact, W2, xo, A2=T[:, :Rp], B2=Bo, K2=Rp, bias=bo, R=x)),
+ ('fc2b bf16+dgelu(aux)  ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, act='dgelu', aux=u)),
+ ('fc1b bf16 K=3072      ', 2.0*M*d*(ff+Rp), lambda: ops.gemm(gact, W2, dh, A2=T[:, :Rp], B2=Bo, K2=Rp)),
+ ('qkvb bf16 K=2304+96   ', 2.0*M*d*(3*d+3*Rp), lambda: ops.gemm(qkv, rnd(d, 3*d, scale=0.03), dh, A2=T, B2=rnd(d, 3*Rp, scale=0.1), K2=3*Rp)),
+]
+tiles = [int(t) for t in os.environ.get('TILES', '0,2').split(',')]
+for name, fl, fn in cases:
+    res = []
+    for rnd_ in range(3):                      # interleaved rounds in ONE process (cdna guide rule 24)
+        for t in tiles:
+            os.environ['REID_GEMM_TILE'] = str(t)
+            res.append((t, timeit(fn, reps=5)))
+    best = {t: min(u for tt, u in res if tt == t) for t in tiles}
+    print(name + ': ' + '  '.join(f'tile{t}: {best[t]:7.1f} us {fl/best[t]/1e6:6.1f} TF' for t in tiles), flush=True)
