@@ -237,6 +237,23 @@ int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t
 int reid_sgemm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak,
                int64_t sbk, int64_t sbn, int32_t ldc, float alpha, float beta, const float* bias, int32_t act,
                void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Small fp32 pieces of the head: SemanticDisentanglementModule.forward (models/model.py:57-77) and
+ * FeatureFusion.forward (:113-183) on [B,512] / [B,M<=8,512] tensors.
+ *   reid_eltwise_f32: op 0 out=x+alpha*y, 1 relu(x), 2 relu' (x pre-activation, y = dy), 3 erf-GELU(x),
+ *                     4 y*GELU'(x), 5 x*y, 6 nan_to_num(x, 0, 1e4, -1e4) (model.py:165)
+ *   reid_small_attn_fwd/bwd: softmax(q k^T / 8 + key-padding mask) v over S <= 8 tokens, head_dim 64, fp32
+ *                     (nn.MultiheadAttention, model.py:152-155); qkv [n_seq*S, ld] = q|k|v; probs [n_seq, heads, 8, 8] saved
+ *   reid_masked_mean: out[b,:] = sum_m mask[b,m] x[b,m,:] / max(sum_m mask[b,m], 1) (model.py:168-178); backward != 0:
+ *                     x = dout [B,D], out = dx [B,M,D]
+ * ------------------------------------------------------------------------------------------ */
+int reid_eltwise_f32(int32_t op, const float* x, const float* y, float* out, int64_t n, float alpha, void* stream);
+int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, float* out, int32_t ldo, float* probs,
+                        int32_t n_seq, int32_t S, int32_t heads, void* stream);
+int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* dout, int32_t ldo, float* dqkv,
+                        int32_t lddqkv, int32_t n_seq, int32_t S, int32_t heads, void* stream);
+int reid_masked_mean(const float* x, const float* mask, float* out, int32_t B, int32_t M, int32_t D, int32_t backward,
+                     void* stream);
 /* L2-normalise rows (F.normalize, train.py:442): x f32 [rows, D] -> y f32 and/or bf16. */
 int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t D,
                      float eps, float scale, void* stream);

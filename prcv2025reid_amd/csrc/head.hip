@@ -381,6 +381,123 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ small fp32 helpers of the head
+// (SDM module models/model.py:57-77 and FeatureFusion :113-183 work on [B,512] / [B,5,512] tensors: latency bound)
+__global__ void eltwise_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = x[i];
+        float r;
+        switch (op) {
+            case 0: r = a + alpha * y[i]; break;                       // add
+            case 1: r = fmaxf(a, 0.f); break;                          // relu
+            case 2: r = a > 0.f ? y[i] : 0.f; break;                   // relu backward: x = pre-activation, y = dy
+            case 3: r = gelu_erf_f(a); break;                          // gelu
+            case 4: r = y[i] * dgelu_erf_f(a); break;                  // gelu backward
+            case 5: r = a * y[i]; break;                               // mul
+            default: r = isfinite(a) ? a : (a != a ? 0.f : (a > 0.f ? 1e4f : -1e4f)); break;   // 6: nan_to_num(0, 1e4, -1e4)
+        }
+        out[i] = r;
+    }
+}
+
+// Attention over S <= 8 tokens, head_dim 64, fp32 (nn.MultiheadAttention of FeatureFusion, model.py:152-155).
+// One wave per (sequence, head); lane = one of the 64 head dimensions; scores by wave reductions.
+__global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __restrict__ qkv, int ld, const uint8_t* __restrict__ key_mask,
+                                                             float* __restrict__ out, int ldo, float* __restrict__ probs, int n_seq,
+                                                             int S, int heads) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_seq * heads) return;
+    const int seq = item / heads, head = item % heads, d = heads * 64;
+    float q[8], k[8], v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float* r = qkv + (size_t)(seq * S + (t < S ? t : 0)) * ld + head * 64 + lane;
+        q[t] = r[0]; k[t] = r[d]; v[t] = r[2 * d];
+    }
+    float* pr = probs + (size_t)item * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= S) break;
+        float sc[8], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sj = wave_sum(q[i] * k[j]) * 0.125f;
+            const bool ok = j < S && (!key_mask || key_mask[seq * S + j] != 0);
+            sc[j] = ok ? sj : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] /= den; o += sc[j] * v[j]; if (lane == j) pr[i * 8 + j] = sc[j]; }
+        out[(size_t)(seq * S + i) * ldo + head * 64 + lane] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ probs,
+                                                             const float* __restrict__ dout, int ldo, float* __restrict__ dqkv, int lddq,
+                                                             int n_seq, int S, int heads) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_seq * heads) return;
+    const int seq = item / heads, head = item % heads, d = heads * 64;
+    float q[8], k[8], v[8], go[8], dq[8], dk[8], dv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const size_t row = (size_t)(seq * S + (t < S ? t : 0));
+        const float* r = qkv + row * ld + head * 64 + lane;
+        q[t] = r[0]; k[t] = r[d]; v[t] = r[2 * d];
+        go[t] = t < S ? dout[row * ldo + head * 64 + lane] : 0.f;
+        dq[t] = 0.f; dk[t] = 0.f; dv[t] = 0.f;
+    }
+    const float* pr = probs + (size_t)item * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= S) break;
+        float p[8], dp[8], dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p[j] = j < S ? pr[i * 8 + j] : 0.f;
+            dp[j] = wave_sum(go[i] * v[j]);
+            dot += p[j] * dp[j];
+            dv[j] += p[j] * go[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ds = p[j] * (dp[j] - dot) * 0.125f;
+            dq[i] += ds * k[j];
+            dk[j] += ds * q[i];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < S) {
+            float* r = dqkv + (size_t)(seq * S + t) * lddq + head * 64 + lane;
+            r[0] = dq[t]; r[d] = dk[t]; r[2 * d] = dv[t];
+        }
+}
+
+// out[b,:] = sum_m mask[b,m] x[b,m,:] / max(sum_m mask[b,m], 1)   (model.py:168-178);  bwd: dx[b,m,:] = mask[b,m] dout[b,:] / cnt
+__global__ void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int B, int M, int D, int bwd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D) return;
+    const int b = i / D, c = i % D;
+    float cnt = 0.f;
+    for (int m = 0; m < M; ++m) cnt += mask[b * M + m];
+    cnt = fmaxf(cnt, 1.f);
+    if (!bwd) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += mask[b * M + m] * x[((size_t)b * M + m) * D + c];
+        out[i] = s / cnt;
+    } else {
+        const float g = x[i] / cnt;      // x = dout [B, D]
+        for (int m = 0; m < M; ++m) out[((size_t)b * M + m) * D + c] = mask[b * M + m] * g;
+    }
+}
+
 int launch_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn, int ldc,
                  float alpha, float beta, const float* bias, int act, hipStream_t s) {
     hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc,
@@ -524,5 +641,41 @@ extern "C" int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t
     if ((rc = launch_sgemm(S, qn, tmp, Mg, D, N, 1, Mg, D, 1, D, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((Mg + 3) / 4), dim3(256), 0, s, g, ldg, tmp, D, dg, lddg, Mg, D, 1e-8f, 1);
     REID_CHECK_LAUNCH("reid_sdm_bwd(dg)");
+    return REID_OK;
+}
+
+extern "C" int reid_eltwise_f32(int32_t op, const float* x, const float* y, float* out, int64_t n, float alpha, void* stream) {
+    REID_CHECK_ARG(x && out && n > 0 && op >= 0 && op <= 6, "reid_eltwise_f32: bad args");
+    REID_CHECK_ARG(y || op == 1 || op == 3 || op == 6, "reid_eltwise_f32: op %d needs a second operand", op);
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(eltwise_kernel, dim3((int)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, op, x, y, out, (long)n, alpha);
+    REID_CHECK_LAUNCH("reid_eltwise_f32");
+    return REID_OK;
+}
+
+extern "C" int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, float* out, int32_t ldo, float* probs,
+                                   int32_t n_seq, int32_t S, int32_t heads, void* stream) {
+    REID_CHECK_ARG(qkv && out && probs && n_seq > 0 && S >= 1 && S <= 8 && heads > 0 && ld >= 3 * heads * 64 && ldo >= heads * 64,
+                   "reid_small_attn_fwd: bad args (S=%d must be 1..8)", S);
+    hipLaunchKernelGGL(small_attn_fwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, key_mask, out, ldo,
+                       probs, n_seq, S, heads);
+    REID_CHECK_LAUNCH("reid_small_attn_fwd");
+    return REID_OK;
+}
+
+extern "C" int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* dout, int32_t ldo, float* dqkv,
+                                   int32_t lddqkv, int32_t n_seq, int32_t S, int32_t heads, void* stream) {
+    REID_CHECK_ARG(qkv && probs && dout && dqkv && n_seq > 0 && S >= 1 && S <= 8 && heads > 0, "reid_small_attn_bwd: bad args");
+    hipLaunchKernelGGL(small_attn_bwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, probs, dout, ldo,
+                       dqkv, lddqkv, n_seq, S, heads);
+    REID_CHECK_LAUNCH("reid_small_attn_bwd");
+    return REID_OK;
+}
+
+extern "C" int reid_masked_mean(const float* x, const float* mask, float* out, int32_t B, int32_t M, int32_t D, int32_t backward, void* stream) {
+    REID_CHECK_ARG(x && mask && out && B > 0 && M > 0 && D > 0, "reid_masked_mean: bad args");
+    const long n = (long)B * D;
+    hipLaunchKernelGGL(masked_mean_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, out, B, M, D, backward);
+    REID_CHECK_LAUNCH("reid_masked_mean");
     return REID_OK;
 }

@@ -109,3 +109,142 @@ class SDMFn(torch.autograd.Function):
         dq = torch.zeros_like(q); dg = torch.zeros_like(g)
         ops.sdm_bwd(q, g, ql, gl, qv, gv, ctx.tau, ws, dloss.reshape(1).float().contiguous(), dq, dg)
         return dq, dg, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Small fp32 pieces of SemanticDisentanglementModule (models/model.py:57-77) and FeatureFusion (:113-183)
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.eltwise('add', a.contiguous().float(), b.contiguous().float())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class ActFn(torch.autograd.Function):
+    """relu / gelu (exact erf form) with the matching derivative kernels."""
+
+    @staticmethod
+    def forward(ctx, x, kind: str):
+        x = x.contiguous().float()
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return ops.eltwise(kind, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.eltwise(ctx.kind + '_bwd', x, g.contiguous().float()), None
+
+
+class NanToNumFn(torch.autograd.Function):
+    """torch.nan_to_num(x, nan=0, posinf=1e4, neginf=-1e4) (model.py:165); the gradient passes where x is finite."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        ctx.save_for_backward(x)
+        return ops.eltwise('nan_to_num', x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.isfinite(x)
+
+
+class LayerNormF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps: float):
+        shp = x.shape
+        x2 = x.contiguous().float().view(-1, shp[-1])
+        y = torch.empty_like(x2)
+        mean = torch.empty(x2.shape[0], device=x2.device); rstd = torch.empty_like(mean)
+        ops.layernorm_fwd(x2, w.detach(), b.detach(), y_f32=y, mean=mean, rstd=rstd, eps=eps)
+        ctx.save_for_backward(x2, w.detach(), mean, rstd)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, mean, rstd = ctx.saved_tensors
+        g2 = g.contiguous().float().view(x2.shape)
+        dx = torch.empty_like(x2)
+        dw = torch.zeros_like(w); db = torch.zeros_like(w)
+        ops.layernorm_bwd(g2, x2, w, mean, rstd, dx, dgamma=dw, dbeta=db)
+        return dx.view(ctx.shp), dw, db, None
+
+
+class LinearNdF32Fn(torch.autograd.Function):
+    """y = x @ W.T + b for x of any leading shape, exact fp32 (vector-ALU GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        shp = x.shape
+        x2 = x.contiguous().float().view(-1, shp[-1])
+        W = W.detach().contiguous()
+        y = torch.empty(x2.shape[0], W.shape[0], device=x2.device)
+        ops.sgemm(x2, W, y, tb=True, bias=None if b is None else b.detach().contiguous())
+        ctx.save_for_backward(x2, W)
+        ctx.shp = shp; ctx.has_bias = b is not None
+        return y.view(shp[:-1] + (W.shape[0],))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W = ctx.saved_tensors
+        g2 = g.contiguous().float().view(x2.shape[0], W.shape[0])
+        dx = torch.empty_like(x2)
+        ops.sgemm(g2, W, dx)
+        dW = torch.empty_like(W)
+        ops.sgemm(g2, x2, dW, ta=True)
+        db = None
+        if ctx.has_bias:
+            ones = torch.ones(1, g2.shape[0], device=g2.device)
+            db = torch.empty(1, W.shape[0], device=g2.device)
+            ops.sgemm(ones, g2, db)
+            db = db.view(-1)
+        return dx.view(ctx.shp), dW, db
+
+
+class SmallAttnFn(torch.autograd.Function):
+    """softmax(q k^T / 8 + key padding) v over S <= 8 tokens (nn.MultiheadAttention core, head_dim 64), fp32."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, n_seq: int, S: int, heads: int):
+        qkv = qkv.contiguous().float()
+        d = heads * 64
+        out = torch.empty(n_seq * S, d, device=qkv.device)
+        probs = torch.zeros(n_seq * heads * 64, device=qkv.device)
+        ops.small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads)
+        ctx.save_for_backward(qkv, probs)
+        ctx.dims = (n_seq, S, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, probs = ctx.saved_tensors
+        n_seq, S, heads = ctx.dims
+        dqkv = torch.empty_like(qkv)
+        ops.small_attn_bwd(qkv, probs, g.contiguous().float(), dqkv, n_seq, S, heads)
+        return dqkv, None, None, None, None
+
+
+class MaskedMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        B, M, D = x.shape
+        x = x.contiguous().float(); mask = mask.contiguous().float()
+        out = torch.empty(B, D, device=x.device)
+        ops.masked_mean(x, mask, out, B, M, D)
+        ctx.save_for_backward(mask)
+        ctx.dims = (B, M, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        B, M, D = ctx.dims
+        dx = torch.empty(B, M, D, device=g.device)
+        ops.masked_mean(g.contiguous().float(), mask, dx, B, M, D, backward=True)
+        return dx, None

@@ -27,12 +27,12 @@ from typing import Any, Dict, List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from .config import arch_of
 from .engine import Engine, LoraLayout, VisionEncodeFn
-from .head import BNNeckFn, CrossEntropyLSFn, LinearF32Fn, SDMFn
+from .head import (ActFn, AddFn, BNNeckFn, CrossEntropyLSFn, LayerNormF32Fn, LinearF32Fn, LinearNdF32Fn, MaskedMeanFn,
+                   NanToNumFn, SDMFn, SmallAttnFn)
 from .tokenizer import load_tokenizer
 from .weights import param_spec, seeded_tensor, is_dead_key
 
@@ -251,57 +251,53 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         ids, am = self._tokens(texts)
         return self.engine.text_forward(ids, am)
 
-    # ------------------------------------------------------------------ head modules kept in torch (tiny, [B,512])
+    # ------------------------------------------------------------------ head modules ([B,512] / [B,M,512], fp32 HIP kernels)
     def _sdm_module(self, x):
         """SemanticDisentanglementModule.forward, models/model.py:57-77 (length-1 MHA == out_proj(v_proj(x)))."""
         P, D = self._ref, self.fusion_dim
+        lin = LinearNdF32Fn.apply
         wv = P['sdm_module.semantic_attn.in_proj_weight'][2 * D:]; bv = P['sdm_module.semantic_attn.in_proj_bias'][2 * D:]
-        a = F.linear(F.linear(x, wv, bv), P['sdm_module.semantic_attn.out_proj.weight'], P['sdm_module.semantic_attn.out_proj.bias'])
-        y = F.linear(x + a, P['sdm_module.semantic_proj.0.weight'], P['sdm_module.semantic_proj.0.bias'])
-        y = F.relu(F.layer_norm(y, (y.shape[-1],), P['sdm_module.semantic_proj.1.weight'], P['sdm_module.semantic_proj.1.bias']))
-        return F.linear(y, P['sdm_module.semantic_proj.4.weight'], P['sdm_module.semantic_proj.4.bias'])
+        a = lin(lin(x, wv, bv), P['sdm_module.semantic_attn.out_proj.weight'], P['sdm_module.semantic_attn.out_proj.bias'])
+        y = lin(AddFn.apply(x, a), P['sdm_module.semantic_proj.0.weight'], P['sdm_module.semantic_proj.0.bias'])
+        y = LayerNormF32Fn.apply(y, P['sdm_module.semantic_proj.1.weight'], P['sdm_module.semantic_proj.1.bias'], 1e-5)
+        return lin(ActFn.apply(y, 'relu'), P['sdm_module.semantic_proj.4.weight'], P['sdm_module.semantic_proj.4.bias'])
 
     def _fusion(self, features: List[torch.Tensor], masks: Optional[List[torch.Tensor]] = None):
-        """FeatureFusion.forward, models/model.py:113-183."""
+        """FeatureFusion.forward, models/model.py:113-183.  stack / where / cat below only move data; every arithmetic
+        step is a HIP kernel (fp32)."""
         if len(features) == 0:
             raise ValueError('No features to fuse')
         if len(features) == 1:
             return features[0]
         P, D = self._ref, self.fusion_dim
         heads = self.arch['fusion_num_heads']
-        x = torch.stack(features, dim=1)
+        lin, ln = LinearNdF32Fn.apply, LayerNormF32Fn.apply
+        x = torch.stack(features, dim=1).float()
         B, M, _ = x.shape
-        sm = None; add = None
+        sm = None; km = None
         if masks is not None:
-            sm = torch.stack(masks, dim=1).to(x.device)
-            pad = ~sm.bool()
+            sm = torch.stack(masks, dim=1).to(x.device).float()
+            pad = sm <= 0
             dead = pad.all(dim=1)
-            # all-masked rows: unmask slot 0 and put the mean of the live rows there (model.py:141-149), sync-free
-            live = (~dead).float().view(B, 1, 1)
-            denom = (live.sum() * M).clamp_min(1.0)
-            gm = (x * live).sum(dim=(0, 1)) / denom
-            x = torch.cat([torch.where(dead.view(B, 1), gm.view(1, D).expand(B, D), x[:, 0]).unsqueeze(1), x[:, 1:]], dim=1)
+            # all-masked rows: unmask slot 0 and put the mean of the live rows there (model.py:141-149), sync-free:
+            # gm = masked mean over all (sample, slot) pairs of live samples
+            live = (~dead).float().view(1, B, 1).expand(1, B, M).reshape(1, B * M)
+            gm = MaskedMeanFn.apply(x.reshape(1, B * M, D), live)                     # [1, D]
+            x = torch.cat([torch.where(dead.view(B, 1), gm.expand(B, D), x[:, 0]).unsqueeze(1), x[:, 1:]], dim=1)
             pad = torch.cat([(pad[:, 0] & ~dead).unsqueeze(1), pad[:, 1:]], dim=1)
-            add = torch.zeros(B, 1, 1, M, device=x.device).masked_fill(pad.view(B, 1, 1, M), float('-inf'))
-        w, b = P['feature_fusion.multihead_attn.in_proj_weight'], P['feature_fusion.multihead_attn.in_proj_bias']
-        q, k, v = F.linear(x, w, b).split(D, dim=-1)
-        hd = D // heads
-        sh = lambda t: t.view(B, M, heads, hd).transpose(1, 2)
-        s = (sh(q) @ sh(k).transpose(-1, -2)) * (hd ** -0.5)
-        if add is not None:
-            s = s + add
-        a = (torch.softmax(s, dim=-1) @ sh(v)).transpose(1, 2).reshape(B, M, D)
-        a = F.linear(a, P['feature_fusion.multihead_attn.out_proj.weight'], P['feature_fusion.multihead_attn.out_proj.bias'])
-        y = F.layer_norm(x + a, (D,), P['feature_fusion.norm1.weight'], P['feature_fusion.norm1.bias'])
-        m = F.layer_norm(y, (D,), P['feature_fusion.mlp.0.weight'], P['feature_fusion.mlp.0.bias'])
-        m = F.linear(F.gelu(F.linear(m, P['feature_fusion.mlp.1.weight'], P['feature_fusion.mlp.1.bias'])),
-                     P['feature_fusion.mlp.4.weight'], P['feature_fusion.mlp.4.bias'])
-        z = F.layer_norm(y + m, (D,), P['feature_fusion.norm2.weight'], P['feature_fusion.norm2.bias'])
-        z = torch.nan_to_num(z, nan=0.0, posinf=1e4, neginf=-1e4)
+            km = (~pad).to(torch.uint8).contiguous()
+        qkv = lin(x.reshape(B * M, D), P['feature_fusion.multihead_attn.in_proj_weight'], P['feature_fusion.multihead_attn.in_proj_bias'])
+        a = SmallAttnFn.apply(qkv, km, B, M, heads)
+        a = lin(a, P['feature_fusion.multihead_attn.out_proj.weight'], P['feature_fusion.multihead_attn.out_proj.bias'])
+        y = ln(AddFn.apply(x.reshape(B * M, D), a), P['feature_fusion.norm1.weight'], P['feature_fusion.norm1.bias'], 1e-5)
+        m = ln(y, P['feature_fusion.mlp.0.weight'], P['feature_fusion.mlp.0.bias'], 1e-5)
+        m = ActFn.apply(lin(m, P['feature_fusion.mlp.1.weight'], P['feature_fusion.mlp.1.bias']), 'gelu')
+        m = lin(m, P['feature_fusion.mlp.4.weight'], P['feature_fusion.mlp.4.bias'])
+        z = ln(AddFn.apply(y, m), P['feature_fusion.norm2.weight'], P['feature_fusion.norm2.bias'], 1e-5)
+        z = NanToNumFn.apply(z).view(B, M, D)
         if sm is None:
-            return z.mean(dim=1)
-        cnt = sm.sum(dim=1, keepdim=True).float().clamp(min=1.0)
-        return (z * sm.unsqueeze(-1).float()).sum(dim=1) / cnt
+            sm = torch.ones(B, M, device=x.device)
+        return MaskedMeanFn.apply(z, sm)
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: Optional[Dict[str, torch.Tensor]] = None, texts=None,

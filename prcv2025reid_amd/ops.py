@@ -229,3 +229,28 @@ def cosine_topk(Qb, Gb, Qf, Gf, k, ws, out_idx, out_score, exclude_q=None, exclu
 def cosine_topk_exact(Qf, Gf, k, scratch, out_idx, out_score, exclude_q=None, exclude_g=None):
     check(lib().reid_cosine_topk_exact(ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k, ptr(exclude_q),
                                        ptr(exclude_g), ptr(scratch), ptr(out_idx), ptr(out_score), stream_ptr()))
+
+
+# ----------------------------------------------------------------------------------------- small fp32 head pieces
+ELT = {'add': 0, 'relu': 1, 'relu_bwd': 2, 'gelu': 3, 'gelu_bwd': 4, 'mul': 5, 'nan_to_num': 6}
+
+
+def eltwise(op, x, y=None, out=None, alpha=1.0):
+    out = torch.empty_like(x) if out is None else out
+    check(lib().reid_eltwise_f32(ELT[op], ptr(x), ptr(y), ptr(out), C.c_int64(x.numel()), C.c_float(alpha), stream_ptr()))
+    return out
+
+
+def small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads):
+    check(lib().reid_small_attn_fwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), out.stride(0), ptr(probs), n_seq, S, heads,
+                                    stream_ptr()))
+
+
+def small_attn_bwd(qkv, probs, dout, dqkv, n_seq, S, heads):
+    check(lib().reid_small_attn_bwd(ptr(qkv), qkv.stride(0), ptr(probs), ptr(dout), dout.stride(0), ptr(dqkv), dqkv.stride(0),
+                                    n_seq, S, heads, stream_ptr()))
+
+
+def masked_mean(x, mask, out, B, M, D, backward=False):
+    check(lib().reid_masked_mean(ptr(x), ptr(mask), ptr(out), B, M, D, int(backward), stream_ptr()))
+    return out

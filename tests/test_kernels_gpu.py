@@ -373,3 +373,58 @@ def test_cosine_topk_matches_fp32_stable_argsort(ops, Nq, Ng, k):
             assert abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
     if k >= 3:
         assert idx[0, :3].tolist() == [3, 5, 100]
+
+
+def test_small_head_kernels(ops):
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd import head as H
+    g = torch.Generator(device='cuda').manual_seed(11)
+    B, M, D, heads = 9, 5, 512, 8
+    # small attention vs the oracle's attention_core with a key-padding mask
+    qkv = torch.randn(B * M, 3 * D, device='cuda', generator=g)
+    km = (torch.rand(B, M, device='cuda', generator=g) > 0.4).to(torch.uint8); km[:, 0] = 1
+    qc = qkv.cpu().requires_grad_(True)
+    q, k, v = [t.view(B, M, D) for t in qc.split(D, dim=1)]
+    add = torch.zeros(B, 1, 1, M).masked_fill(~km.cpu().bool().view(B, 1, 1, M), float('-inf'))
+    ref = O.attention_core(q, k, v, heads, add).reshape(B * M, D)
+    qg = qkv.clone().requires_grad_(True)
+    out = H.SmallAttnFn.apply(qg, km, B, M, heads)
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    w = torch.randn(B * M, D, generator=torch.Generator().manual_seed(1))
+    (ref * w).sum().backward(); (out * w.cuda()).sum().backward()
+    assert rel_err(qg.grad.cpu(), qc.grad) < 1e-4
+    # masked mean, activations, add, layernorm, linear
+    x = torch.randn(B, M, D, device='cuda', generator=g).requires_grad_(True)
+    mk = km.float()
+    mm = H.MaskedMeanFn.apply(x, mk)
+    refmm = (x.detach() * mk.unsqueeze(-1)).sum(1) / mk.sum(1, keepdim=True).clamp(min=1)
+    assert rel_err(mm.detach(), refmm) < 1e-6
+    mm.sum().backward()
+    assert rel_err(x.grad, (mk / mk.sum(1, keepdim=True).clamp(min=1)).unsqueeze(-1).expand(B, M, D)) < 1e-6
+    for kind, fn in (('relu', torch.relu), ('gelu', torch.nn.functional.gelu)):
+        a = torch.randn(300, 512, device='cuda', generator=g).requires_grad_(True)
+        b2 = a.detach().clone().requires_grad_(True)
+        y = H.ActFn.apply(a, kind); yr = fn(b2)
+        assert rel_err(y.detach(), yr.detach()) < 2e-6
+        y.sum().backward(); yr.sum().backward()
+        assert rel_err(a.grad, b2.grad) < 2e-6
+    W = torch.randn(700, 512, device='cuda', generator=g).requires_grad_(True); bb = torch.randn(700, device='cuda', generator=g).requires_grad_(True)
+    xin = torch.randn(B, M, 512, device='cuda', generator=g).requires_grad_(True)
+    y = H.LinearNdF32Fn.apply(xin, W, bb)
+    W2, b3, x2 = [t.detach().clone().requires_grad_(True) for t in (W, bb, xin)]
+    yr = torch.nn.functional.linear(x2, W2, b3)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    wgt = torch.randn_like(yr)
+    (y * wgt).sum().backward(); (yr * wgt).sum().backward()
+    assert rel_err(xin.grad, x2.grad) < 1e-5 and rel_err(W.grad, W2.grad) < 1e-5 and rel_err(bb.grad, b3.grad) < 1e-5
+    lw = (1 + 0.1 * torch.randn(512, device='cuda', generator=g)).requires_grad_(True); lb = torch.randn(512, device='cuda', generator=g).requires_grad_(True)
+    x3 = torch.randn(B * M, 512, device='cuda', generator=g).requires_grad_(True)
+    y = H.LayerNormF32Fn.apply(x3, lw, lb, 1e-5)
+    lw2, lb2, x4 = [t.detach().clone().requires_grad_(True) for t in (lw, lb, x3)]
+    yr = torch.nn.functional.layer_norm(x4, (512,), lw2, lb2, 1e-5)
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    w3 = torch.randn(B * M, 512, device='cuda', generator=g)
+    (y * w3).sum().backward(); (yr * w3).sum().backward()
+    assert rel_err(x3.grad, x4.grad) < 1e-4 and rel_err(lw.grad, lw2.grad) < 1e-4 and rel_err(lb.grad, lb2.grad) < 1e-4
+    t = torch.tensor([1.0, float('nan'), float('inf'), -float('inf')], device='cuda')
+    assert H.NanToNumFn.apply(t).tolist() == [1.0, 0.0, 1e4, -1e4]
