@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.3 TB/s measured float4 copy), same guide
 FLOP_PER_INSTANCE = 292.0e9    # fwd 148.25 + bwd (frozen backbone) 143.76 GFLOP at r=8, T=77
 
 
@@ -49,6 +50,19 @@ def parse():
     ap.add_argument('--no-retrieval', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     return ap.parse_args()
+
+
+def pmc_traffic(*kernels):
+    """Launch-weighted HBM bytes per launch of `kernels` from the committed PMC summary (collected with separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide prescribes)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    n = sum(d[k]['launches'] for k in kernels if k in d)
+    if n == 0:
+        return None
+    return sum(d[k]['traffic_bytes_per_launch'] * d[k]['launches'] for k in kernels if k in d) / n
 
 
 def cpu_baseline():
@@ -92,29 +106,26 @@ def cpu_baseline():
 
 
 def retrieval_bench(dev):
-    from prcv2025reid_amd import ops
+    from prcv2025reid_amd.retrieval import GalleryIndex
     Nq, Ng, D, k = 10000, 200000, 512, 10
     g = torch.Generator(device=dev).manual_seed(2)
     Q = torch.nn.functional.normalize(torch.randn(Nq, D, device=dev, generator=g), dim=1)
     G = torch.nn.functional.normalize(torch.randn(Ng, D, device=dev, generator=g), dim=1)
-    Qb, Gb = ops.to_bf16(Q), ops.to_bf16(G)
-    ws = torch.empty(ops.topk_ws_bytes(Nq, Ng, k), device=dev, dtype=torch.uint8)
-    idx = torch.empty(Nq, k, device=dev, dtype=torch.int32); sc = torch.empty(Nq, k, device=dev)
+    index = GalleryIndex(G, normalized=True)           # gallery resident in HBM (fp32 + 16-bit copies)
     for _ in range(2):
-        ops.cosine_topk(Qb, Gb, Q, G, k, ws, idx, sc)
+        idx, sc = index.topk(Q, k=k, normalized=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        ops.cosine_topk(Qb, Gb, Q, G, k, ws, idx, sc)
+        idx, sc = index.topk(Q, k=k, normalized=True)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
-    flagged = int((idx[:, 0] == -2).sum())
-    # spot check of exactness on 64 queries against fp32 matmul + stable argsort
+    # exactness spot check on 64 queries against fp32 matmul + stable argsort
     ref = torch.argsort((Q[:64] @ G.t()), dim=1, descending=True, stable=True)[:, :k]
     exact = bool((ref == idx[:64].long()).all())
     return {'queries_per_s': Nq / t, 'ms': t * 1e3, 'Nq': Nq, 'Ng': Ng, 'D': D, 'k': k, 'tflops': 2.0 * Nq * Ng * D / t / 1e12,
-            'overflow_flagged': flagged, 'top10_equals_fp32_argsort_on_64_queries': exact}
+            'compulsory_bytes': (Nq + Ng) * D * 2 + Nq * k * 4, 'top10_equals_fp32_argsort_on_64_queries': exact}
 
 
 def main():
@@ -169,8 +180,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_events:
-        ops.gemm_profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         L = step()
@@ -179,7 +188,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ops.gemm_profile_end() if not args.no_kernel_events else []
+    # Kernel-duration pass for the roofline: the SAME K steps again, now with a HIP event pair around every launch of the
+    # dominant kernels on the launch stream.  It is a second pass because timing events are not free here: each record is a
+    # system-scope fence (L2 write-back), which slowed the step by 15-25 % when taken inside the throughput region.
+    prof, ln_prof = [], []
+    if not args.no_kernel_events:
+        ops.gemm_profile_begin(); ops.ln_profile_begin()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ms_with_events = (time.perf_counter() - te) / args.steps * 1e3
+        prof = ops.gemm_profile_end(); ln_prof = ops.ln_profile_end()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,9 +224,17 @@ def main():
             fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
             ach = fl / (ms * 1e-3) / 1e12
             res['roofline'] = {'kernel': 'mer_gemm_kernel<256,256,2,4> + <128,256,2,4>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None, 'launches': len(prof),
-                               'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<256, 256, 2, 4>', 'mer_gemm_kernel<128, 256, 2, 4>'),
+                               'traffic_note': 'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic.md); null if not collected',
+                               'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
+                               'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
                                'flops_per_launch_avg': fl / len(prof)}
+        if ln_prof:
+            nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
+            gbs = nb / (ms * 1e-3) / 1e9
+            res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
+                                   'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
         if world == 1 and not args.no_retrieval:
             del opt
             torch.cuda.empty_cache()

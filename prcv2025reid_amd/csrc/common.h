@@ -45,7 +45,7 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
 #define REID_FLAVOR_ID 1
-#define REID_T16_EPS 0.00048828125f      /* 2^-11 relative rounding error */
+#define REID_T16_EPS 0.0009765625f       /* 2u = 2^-10: bound of |q~.g~ - q.g| for unit vectors rounded to f16 (u = 2^-11) */
 #else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserved (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
@@ -56,7 +56,7 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 #define REID_FLAVOR_ID 0
-#define REID_T16_EPS 0.00390625f         /* 2^-8 */
+#define REID_T16_EPS 0.00390625f         /* 2u = 2^-8 for bf16 (u = 2^-9) */
 #endif
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {

@@ -19,7 +19,7 @@ namespace {
 
 using namespace gemmcore;
 
-constexpr float EPS_BF16 = 2.0f * REID_T16_EPS * 1.01f;   // |q~.g~ - q.g| <= 2*eps16 (+1 %) for unit q, g rounded to the 16-bit format
+constexpr float EPS_BF16 = REID_T16_EPS * 1.01f;   // |q~.g~ - q.g| <= 2u (+1 %) for unit q, g rounded to the 16-bit format (Cauchy-Schwarz)
 
 struct TopkParams {
     const bf16_t* Q; const bf16_t* G;
@@ -171,20 +171,20 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Q
     }
 }
 
-// exact brute force for flagged queries: one block per query, fp32 throughout
-__global__ __launch_bounds__(256) void brute_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng, int D,
-                                                    const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int k,
-                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_score, float* __restrict__ scratch) {
-    const int q = blockIdx.x;
+// exact brute force for flagged queries, fp32 throughout: (1) scores of every gallery row, 64 workgroups per query;
+// (2) one workgroup per query extracts the k best by (score desc, index asc)
+__global__ __launch_bounds__(256) void brute_score_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng, int D,
+                                                          const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int k,
+                                                          const int32_t* __restrict__ out_idx, float* __restrict__ scratch) {
+    const int q = blockIdx.y;
     if (out_idx[(size_t)q * k] != -2) return;
     __shared__ float qrow[1024];
-    __shared__ float rbest[4]; __shared__ int ridx[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
     __syncthreads();
     float* sc = scratch + (size_t)q * Ng;
     const int eq = exq ? exq[q] : -1;
-    for (int gi = w; gi < Ng; gi += 4) {
+    for (int gi = blockIdx.x * 4 + w; gi < Ng; gi += gridDim.x * 4) {
         const float* g = Gf + (size_t)gi * D;
         float s = 0.f;
         for (int i = lane * 4; i < D; i += 256) {
@@ -195,7 +195,15 @@ __global__ __launch_bounds__(256) void brute_kernel(const float* __restrict__ Qf
         if (eq >= 0 && exg[gi] == eq) s = -1e9f;
         if (lane == 0) sc[gi] = s;
     }
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void brute_select_kernel(int Ng, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                           float* __restrict__ scratch) {
+    const int q = blockIdx.x;
+    if (out_idx[(size_t)q * k] != -2) return;
+    __shared__ float rbest[4]; __shared__ int ridx[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* sc = scratch + (size_t)q * Ng;
     for (int r = 0; r < k; ++r) {
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int gi = tid; gi < Ng; gi += 256) {
@@ -221,10 +229,11 @@ __global__ __launch_bounds__(256) void brute_kernel(const float* __restrict__ Qf
     }
 }
 
-constexpr int SAMPLE = 4096;
+constexpr int SAMPLE = 8192;
 inline int cap_for(int Ng, int k) {
-    // expected survivors ~ k*Ng/SAMPLE (the sample's k-th best is about the (k*Ng/SAMPLE)-th best overall); 4x head-room
-    long c = 4L * k * ((Ng + SAMPLE - 1) / SAMPLE) + 64;
+    // expected survivors ~ k*Ng/SAMPLE (the sample's k-th best is about the (k*Ng/SAMPLE)-th best overall) times ~1.7 for the
+    // 2*eps safety margin; 6x head-room
+    long c = 6L * k * ((Ng + SAMPLE - 1) / SAMPLE) + 64;
     if (c < 256) c = 256;
     if (c > 8192) c = 8192;
     return (int)c;
@@ -269,7 +278,7 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     hipLaunchKernelGGL((score_kernel<BM, BN, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_cosine_topk(sample)");
     static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SAMPLE * 4); attr2 = true; }
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SAMPLE * 4); attr2 = true; }   // 128 KiB: 4 waves x 8192 floats
     hipLaunchKernelGGL(kth_kernel, dim3((Nq + 3) / 4), dim3(256), 4 * ns * sizeof(float), s, dense, ns, ns, k, thr, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(kth)");
     // phase B: filter the whole gallery
@@ -294,7 +303,9 @@ extern "C" int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t 
                                       float* out_score, void* stream) {
     REID_CHECK_ARG(Qf && Gf && scratch && out_idx && out_score && Nq > 0 && Ng > 0 && k > 0 && k <= Ng && D % 4 == 0 && D <= 1024,
                    "reid_cosine_topk_exact: bad args");
-    hipLaunchKernelGGL(brute_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, out_score, scratch);
-    REID_CHECK_LAUNCH("reid_cosine_topk_exact");
+    hipLaunchKernelGGL(brute_score_kernel, dim3(64, Nq), dim3(256), 0, (hipStream_t)stream, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact(score)");
+    hipLaunchKernelGGL(brute_select_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, Ng, k, out_idx, out_score, scratch);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact(select)");
     return REID_OK;
 }

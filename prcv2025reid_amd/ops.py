@@ -17,8 +17,6 @@ ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'quick_gelu': L.ACT_QUICK_GELU, '
 
 # optional per-launch timing of the dominant kernel (bench.py roofline): list of (flops, bytes, start_event, end_event)
 _gemm_profile = None
-
-
 def gemm_profile_begin():
     global _gemm_profile
     _gemm_profile = []
@@ -88,9 +86,36 @@ def layernorm_fwd(x, gamma, beta, y_bf16=None, y_f32=None, mean=None, rstd=None,
                                    y.stride(0), ptr(mean), ptr(rstd), rows, x.shape[1], C.c_float(eps), stream_ptr()))
 
 
+_ln_profile = None
+
+
+def ln_profile_begin():
+    global _ln_profile
+    _ln_profile = []
+
+
+def ln_profile_end():
+    global _ln_profile
+    p, _ln_profile = _ln_profile, None
+    return p
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=None, dres=None, row_index=None, dgamma=None, dbeta=None,
                   rows=None):
     rows = (row_index.shape[0] if row_index is not None else x.shape[0]) if rows is None else rows
+    if _ln_profile is not None and rows >= 4096 and row_index is None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        cols = x.shape[1]
+        # algorithmic bytes per row: dy (2 or 4) + x (4) + dres (4) + dx (4) + 16-bit copy (2)
+        nbytes = rows * cols * ((2 if dy.dtype != torch.float32 else 4) + 4 + (4 if dres is not None else 0) + 4 +
+                                (2 if dx_bf16 is not None else 0))
+        e0.record()
+        check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
+                                       ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
+                                       ptr(dbeta), rows, x.shape[1], stream_ptr()))
+        e1.record()
+        _ln_profile.append((nbytes, e0, e1))
+        return
     check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
                                    ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
                                    ptr(dbeta), rows, x.shape[1], stream_ptr()))

@@ -428,3 +428,21 @@ def test_small_head_kernels(ops):
     assert rel_err(x3.grad, x4.grad) < 1e-4 and rel_err(lw.grad, lw2.grad) < 1e-4 and rel_err(lb.grad, lb2.grad) < 1e-4
     t = torch.tensor([1.0, float('nan'), float('inf'), -float('inf')], device='cuda')
     assert H.NanToNumFn.apply(t).tolist() == [1.0, 0.0, 1e4, -1e4]
+
+
+def test_cosine_topk_overflow_fallback_is_exact(ops):
+    """Thousands of near-duplicates overflow the candidate list: the query is flagged and the exact fp32 pass resolves it."""
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    g = torch.Generator(device='cuda').manual_seed(3)
+    D, Ng, k = 512, 30000, 10
+    base = torch.nn.functional.normalize(torch.randn(1, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    G[10000:20000] = torch.nn.functional.normalize(base + 1e-3 * torch.randn(10000, D, device='cuda', generator=g), dim=1)
+    Q = torch.cat([base, torch.nn.functional.normalize(torch.randn(7, D, device='cuda', generator=g), dim=1)])
+    idx, sc = GalleryIndex(G, normalized=True).topk(Q, k=k, normalized=True)
+    ref = torch.argsort((Q.double() @ G.double().t()).float(), dim=1, descending=True, stable=True)[:, :k]
+    sim = Q.double() @ G.double().t()
+    for qi in range(Q.shape[0]):
+        for r in range(k):
+            a, b = int(ref[qi, r]), int(idx[qi, r])
+            assert a == b or abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
