@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-retrieval', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for rehearsals')
+    ap.add_argument('--compute-dtype', default=None, choices=[None, 'bf16', 'f16'])
     return ap.parse_args()
 
 
@@ -134,10 +136,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)                   # (rehearsal: several ranks may share one GPU under gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     from prcv2025reid_amd import ops
     from prcv2025reid_amd.config import TrainingConfig
     from prcv2025reid_amd.model import CLIPBasedMultiModalReIDModel, apply_reference_freeze
@@ -145,7 +152,8 @@ def main():
     from prcv2025reid_amd.synthetic import synthetic_batch
 
     C = 400
-    cfg = TrainingConfig(device=f'cuda:{local}', mer_lora_rank=args.rank, contrastive_weight=0.1, seed=0)
+    cfg = TrainingConfig(device=f'cuda:{local}', mer_lora_rank=args.rank, contrastive_weight=0.1, seed=0,
+                         compute_dtype=args.compute_dtype)
     model = CLIPBasedMultiModalReIDModel(cfg)
     model.set_num_classes(C)
     apply_reference_freeze(model)
@@ -205,13 +213,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(L['total_loss'].detach())
+    if world > 1:                                  # every rank evaluates the same global loss (parallel.py): check it
+        lt = torch.tensor([loss, -loss], device=dev, dtype=torch.float64)
+        dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+        assert abs(float(lt[0]) + float(lt[1])) < 1e-6 * max(1.0, abs(loss)), 'ranks disagree on the global loss'
     if rank == 0:
         value = world * B * args.steps / elapsed
         res = {
             'metric': 'multimodal instances/sec (PxK, 5-modality) at 1/2/4/8 GPU; eval queries/sec',
             'value': value, 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
+            'dtype': model.compute_dtype, 'data': 'synthetic',
             'config': {'workload': f'P={P},K={K} per GPU, vis/nir/sk/cp 224x224 + text (T<=77), CLIP ViT-B/16 + text tower '
                                    f'random-init, MER-LoRA r={args.rank}, masks {"all-on" if args.mask_drop == 0 else args.mask_drop}, '
                                    f'{C} ids, SDM+CE, fwd+bwd+AdamW (reference default trainable set)',
