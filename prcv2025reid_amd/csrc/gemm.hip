@@ -13,6 +13,7 @@
 // 8/16-byte accesses instead of 2/4-byte ones.
 #include "gemm_core.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -30,19 +31,24 @@ struct GemmParams {
     int c_group, c_group_stride, c_row_off;
     float alpha;
     int tiles_m, tiles_n;
+    int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue
 };
 
 using namespace gemmcore;
 
-// Epilogue of one wave's [TM*16 x TN*16] sub-tile whose first element is C[m_base][n_base].
-// The accumulator layout (lane = one output row, 4 consecutive columns per 16x16 sub-tile) would store 8-byte pieces
-// scattered over 16 rows per instruction (measured: that store tail cost as much as the whole K loop at K = 768).
-// Instead the wave transposes the sub-tile through its own LDS slice `stg`, 16 output rows at a time, and then works
-// on ROW pieces of CW columns per lane (CW = 8 for 16-bit outputs, 4 for fp32 outputs, i.e. always 16-byte stores: the
-// store tail is issue-bound, so halving the instruction count halves it -- cdna_hip_programming.md T21): the lanes of
-// one instruction cover whole contiguous row segments, so bias / residual / aux loads and the C stores are full-line
-// coalesced.  All global operands of the epilogue are requested BEFORE the LDS transposes start.
+// Epilogue of one wave's [TM*16 x TN*16] sub-tile whose first element is C[m_base][n_base], straight from the
+// accumulators (no LDS round trip, no waits between pieces).
+// A lane owns output row m = lane & 15 of each 16-row group and, per group, NP pieces of CW consecutive columns:
+//   MODE 0 (fp32 C): CW = 4, piece pc = MFMA sub-tile pc: columns 16 pc + 4 fq .. +3   (natural accumulator layout)
+//   MODE 1 (16-bit C, weight rows staged through perm32()): CW = 8, columns 8 (4 pc + fq) .. +7
+//   MODE 2 (16-bit C whose strides are not multiples of 8): as MODE 0 with 8-byte stores
+// In modes 0/1 every load/store is 16 bytes per lane and the four lanes fq = 0..3 of one row are adjacent: 64 contiguous
+// bytes per output row per instruction, full 64-byte requests (an earlier version without the permutation stored 8-byte
+// pieces scattered over 16 rows and cost as much as the K loop at K = 768; the LDS-transposing version that replaced it
+// chained LDS write -> wait -> read -> store per 16 rows and ran at ~12 GB/s per CU).
+// Residual / saved-pre-activation operands are prefetched DEPTH row groups ahead (a register ring, indices static after
+// unrolling); all operand loads are unconditional with clamped addresses (no branch, no wait between them).
 template <int CW>
 struct Piece { float v[CW]; };
 
@@ -76,140 +82,130 @@ __device__ __forceinline__ void load_piece(const void* base, int dtype, size_t e
     }
 }
 
-template <int TM, int TN, int CW>
-__device__ __forceinline__ void store_tile_w(const GemmParams& p, f32x4 (&acc)[TN][TM], char* stg, int m_base, int n_base, int lane) {
-    constexpr int WTN = TN * 16;
-    constexpr int PITCH = WTN * 4 + 16;                 // bytes per staged row (+16: conflict-free 16-byte writes)
-    constexpr int LPR = WTN / CW;                       // lanes per staged row
-    constexpr int RPI = 64 / LPR;                       // rows per read instruction
-    static_assert(64 % LPR == 0 && 16 % RPI == 0, "unsupported wave tile width");
-    constexpr int IT = 16 / RPI;                        // read instructions per 16 staged rows
-    constexpr bool PREF = (TM * IT * CW <= 64);         // prefetch residual / aux operands of the whole sub-tile (VGPR budget)
-    const int mrow = lane & 15;
-    const int ncol4 = (lane >> 4) * 4;
-    const int rr = lane / LPR, rc = (lane % LPR) * CW;
-    const int n = n_base + rc;                          // this lane's CW output columns: the same for every row it handles
-    const bool nok = n < p.N;
-    const int nc = nok ? n : 0;                         // clamped: operand loads are unconditional (no branch, no wait between them)
-    const int mlast = p.M - 1;
-    float bv[CW];
+// column of accumulator element (sub-tile j, register r) of lane-quarter fq inside the wave's sub-tile
+template <int MODE>
+__device__ __forceinline__ int acc_col(int j, int r, int fq) {
+    return MODE == 1 ? (((j >> 1) * 4 + fq) * 8 + (j & 1) * 4 + r) : (j * 16 + fq * 4 + r);
+}
+
+// acc := bias (the epilogue then never touches the bias: no registers, no adds)
+template <int TM, int TN, int MODE>
+__device__ __forceinline__ void init_acc_m(const GemmParams& p, f32x4 (&acc)[TN][TM], int n_base, int lane) {
+    const int fq = lane >> 4;
 #pragma unroll
-    for (int e = 0; e < CW; ++e) bv[e] = 0.f;
-    if (p.bias) load_piece<CW>(p.bias, REID_F32, nc, bv);
-    // LoRA routing mask: which of this lane's columns belong to which modality is a per-lane constant
-    int colmod[CW];
-    if (p.mask_r > 0) {
+    for (int j = 0; j < TN; ++j) {
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            int n = n_base + acc_col<MODE>(j, 0, fq);
+            n = n + 3 < p.N ? n : 0;                    // N % 4 == 0: a 4-column run is inside or outside as a whole
+            b = *(const f32x4*)(p.bias + n);
+        }
 #pragma unroll
-        for (int e = 0; e < CW; ++e) colmod[e] = ((nc + e) % p.mask_period) / p.mask_r;
+        for (int i = 0; i < TM; ++i) acc[j][i] = b;
     }
-    Piece<CW> rv[PREF ? TM : 1][PREF ? IT : 1], av[PREF ? TM : 1][PREF ? IT : 1];
-    auto r_off = [&](int m) -> size_t {
+}
+template <int TM, int TN>
+__device__ __forceinline__ void init_acc(const GemmParams& p, f32x4 (&acc)[TN][TM], int n_base, int lane) {
+    if (p.c_dtype != REID_F32 && p.perm_b) init_acc_m<TM, TN, 1>(p, acc, n_base, lane);
+    else init_acc_m<TM, TN, 0>(p, acc, n_base, lane);
+}
+
+template <int TM, int TN, int MODE>
+__device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+    constexpr int CW = MODE == 1 ? 8 : 4;
+    constexpr int NP = TN * 4 / CW;                     // pieces per lane per 16-row group
+    constexpr int NQ = TM * NP;                         // pieces per lane
+    constexpr int RD = (32 / CW) < NQ ? (32 / CW) : NQ; // residual / aux pieces in flight per lane (32 VGPRs of fp32)
+    static_assert(MODE != 1 || TN % 2 == 0, "8-wide pieces pair two MFMA sub-tiles");
+    const int frow = lane & 15, fq = lane >> 4;
+    const int mlast = p.M - 1;
+    const bool has_r = p.R != nullptr;
+    const bool has_aux = p.act >= REID_ACT_DGELU_ERF;
+    Piece<CW> rv[RD];
+    typedef typename std::conditional<CW == 8, bf16x8, bf16x4>::type aux_t;   // saved pre-activations stay packed
+    aux_t av[RD];
+    auto col_of = [&](int pc) { return n_base + (MODE == 1 ? (pc * 4 + fq) * 8 : pc * 16 + fq * 4); };
+    auto fetch = [&](int q, int slot) {
+        const int i = q / NP, pc = q % NP;
+        const int m = m_base + i * 16 + frow;
         const int mc = m < mlast ? m : mlast;
-        return (size_t)(p.r_period > 0 ? mc % p.r_period : mc) * p.ldr + nc;
+        const int n = col_of(pc);
+        const int nc = n < p.N ? n : 0;
+        if (has_r) load_piece<CW>(p.R, p.r_dtype, (size_t)(p.r_period > 0 ? mc % p.r_period : mc) * p.ldr + nc, rv[slot].v);
+        if (has_aux) av[slot] = *(const aux_t*)(p.aux + (size_t)mc * p.ldaux + nc);
     };
-    if (PREF) {
-        if (p.R) {
+    if (has_r || has_aux) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) load_piece<CW>(p.R, p.r_dtype, r_off(m_base + i * 16 + it * RPI + rr), rv[i][it].v);
-        }
-        if (p.act >= REID_ACT_DGELU_ERF) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const int m = m_base + i * 16 + it * RPI + rr;
-                    load_piece<CW>(p.aux, REID_BF16, (size_t)(m < mlast ? m : mlast) * p.ldaux + nc, av[i][it].v);
-                }
-        }
+        for (int q = 0; q < RD; ++q) fetch(q, q);
     }
 #pragma clang loop unroll(full)
-    for (int i = 0; i < TM; ++i) {
+    for (int q = 0; q < NQ; ++q) {
+        const int i = q / NP, pc = q % NP, slot = q % RD;
+        const int m = m_base + i * 16 + frow;
+        const int n = col_of(pc);
+        const bool ok = m < p.M && n < p.N;
+        size_t crow = (size_t)m;
+        if (p.c_group > 0) crow = (size_t)(m / p.c_group) * p.c_group_stride + (m % p.c_group) + p.c_row_off;
+        float v[CW];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) *(f32x4*)(stg + mrow * PITCH + (j * 16 + ncol4) * 4) = acc[j][i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same-wave LDS ops complete in order; stop compiler reordering
+        for (int e = 0; e < CW; ++e) v[e] = acc[MODE == 1 ? 2 * pc + (e >> 2) : pc][i][e & 3];
+        if (has_r) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int r = it * RPI + rr;
-            const int m = m_base + i * 16 + r;
-            float v[CW];
+            for (int e = 0; e < CW; ++e) v[e] += rv[slot].v[e];
+        }
+        if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, v);
+        if (p.act != REID_ACT_NONE) {
+            if (p.act == REID_ACT_GELU_ERF) {               // (uniform branches: only the selected activation is evaluated)
 #pragma unroll
-            for (int q = 0; q < CW / 4; ++q) {
-                const f32x4 t = *(const f32x4*)(stg + r * PITCH + (rc + 4 * q) * 4);
-                v[4 * q] = t[0] + bv[4 * q]; v[4 * q + 1] = t[1] + bv[4 * q + 1];
-                v[4 * q + 2] = t[2] + bv[4 * q + 2]; v[4 * q + 3] = t[3] + bv[4 * q + 3];
+                for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
+            } else if (p.act == REID_ACT_QUICK_GELU) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] = quick_gelu_f(v[e]);
+            } else if (p.act == REID_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == REID_ACT_DGELU_ERF) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[slot][e]));
+            } else if (p.act == REID_ACT_DQUICK_GELU) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] *= dquick_gelu_f(bf16_to_f32((bf16_t)av[slot][e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] *= (bf16_to_f32((bf16_t)av[slot][e]) > 0.f ? 1.f : 0.f);
             }
-            if (p.R) {
-                if (PREF) {
+        }
+        if (p.mask_r > 0) {
+            const int modality = p.img_mod[(m < mlast ? m : mlast) / p.rows_per_img];
+            const int nc = n < p.N ? n : 0;
 #pragma unroll
-                    for (int e = 0; e < CW; ++e) v[e] += rv[PREF ? i : 0][PREF ? it : 0].v[e];
-                } else {
-                    float t[CW];
-                    load_piece<CW>(p.R, p.r_dtype, r_off(m), t);
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) v[e] += t[e];
-                }
-            }
-            const bool ok = m < p.M && nok;
-            size_t crow = (size_t)m;
-            if (p.c_group > 0) crow = (size_t)(m / p.c_group) * p.c_group_stride + (m % p.c_group) + p.c_row_off;
-            if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, v);
-            if (p.act != REID_ACT_NONE) {
-                if (p.act == REID_ACT_GELU_ERF) {           // (uniform branches: only the selected activation is evaluated)
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
-                } else if (p.act == REID_ACT_QUICK_GELU) {
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) v[e] = quick_gelu_f(v[e]);
-                } else if (p.act == REID_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else {
-                    float u[CW];
-                    if (PREF) {
-#pragma unroll
-                        for (int e = 0; e < CW; ++e) u[e] = av[PREF ? i : 0][PREF ? it : 0].v[e];
-                    } else {
-                        load_piece<CW>(p.aux, REID_BF16, (size_t)(m < mlast ? m : mlast) * p.ldaux + nc, u);
-                    }
-                    if (p.act == REID_ACT_DGELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < CW; ++e) v[e] *= dgelu_erf_f(u[e]);
-                    } else if (p.act == REID_ACT_DQUICK_GELU) {
-#pragma unroll
-                        for (int e = 0; e < CW; ++e) v[e] *= dquick_gelu_f(u[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < CW; ++e) v[e] *= (u[e] > 0.f ? 1.f : 0.f);
-                    }
-                }
-            }
-            if (p.mask_r > 0) {
-                const int modality = p.img_mod[(m < mlast ? m : mlast) / p.rows_per_img];
-#pragma unroll
-                for (int e = 0; e < CW; ++e)
-                    if (colmod[e] != modality) v[e] = 0.f;
-            }
+            for (int e = 0; e < CW; ++e)
+                if (((nc + e) % p.mask_period) / p.mask_r != modality) v[e] = 0.f;
+        }
+        if (p.alpha != 1.f) {
 #pragma unroll
             for (int e = 0; e < CW; ++e) v[e] *= p.alpha;
-            if (ok) store_piece<CW>(p.C, p.c_dtype, crow * p.ldc + n, v);
         }
-        asm volatile("" ::: "memory");
+        if (ok) store_piece<CW>(p.C, p.c_dtype, crow * p.ldc + n, v);
+        if ((has_r || has_aux) && q + RD < NQ) fetch(q + RD, slot);
     }
+}
+
+// 16-byte pieces need 16-byte aligned rows in every epilogue operand; perm_b (host side) must match the MODE chosen here
+__host__ __device__ inline bool epilogue_wide16(const GemmParams& p) {
+    return p.c_dtype != REID_F32 && ((p.N | p.ldc) & 7) == 0 && (!p.C2 || (p.ldc2 & 7) == 0) && (!p.R || (p.ldr & 7) == 0) &&
+           (!p.aux || (p.ldaux & 7) == 0);
 }
 
 template <int TM, int TN>
-__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], char* stg, int m_base, int n_base, int lane) {
-    // 16-byte stores in both cases; N % 8 == 0 is needed for the 8-wide form
-    const bool wide = p.c_dtype != REID_F32 && ((p.N | p.ldc) & 7) == 0 && (!p.C2 || (p.ldc2 & 7) == 0) &&
-                      (!p.R || (p.ldr & 7) == 0) && (!p.aux || (p.ldaux & 7) == 0);
-    if (wide) store_tile_w<TM, TN, 8>(p, acc, stg, m_base, n_base, lane);
-    else store_tile_w<TM, TN, 4>(p, acc, stg, m_base, n_base, lane);
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+    if (p.c_dtype == REID_F32) store_tile_m<TM, TN, 0>(p, acc, m_base, n_base, lane);
+    else if (p.perm_b) store_tile_m<TM, TN, 1>(p, acc, m_base, n_base, lane);
+    else store_tile_m<TM, TN, 2>(p, acc, m_base, n_base, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void mer_gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmParams p) {
     using C = Cfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -226,172 +222,162 @@ __global__ __launch_bounds__(WM* WN * 64) void mer_gemm_kernel(const GemmParams 
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
 
     f32x4 acc[C::TN][C::TM];
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc);
+    init_acc<C::TM, C::TN>(p, acc, n0 + wn * (BN / WN), lane);
+    mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
+                             p.perm_b != 0);
 
-    // ------------------------------------------------------------------ epilogue
+    // ------------------------------------------------------------------ epilogue (registers -> global, no LDS)
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    static_assert(C::NW * 16 * (WTN * 4 + 16) <= C::LDS_BYTES, "epilogue staging does not fit");
-    __syncthreads();                                    // all waves are done reading the operand buffers
-    if (p.dbg != 1) store_tile<C::TM, C::TN>(p, acc, smem + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM, n0 + wn * WTN, lane);
+    if (p.dbg != 1) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Persistent, software-pipelined variant (the one the big projections use).
-// One workgroup per CU walks its tiles; the (tile, k-step) pairs of ALL its tiles form one continuous sequence of
-// steps that streams through an NSTAGE-deep LDS ring, so the LDS-DMA loads of the next tile's first K-steps are in
-// flight while the current tile finishes and runs its epilogue -- the per-tile load latency that dominated the
-// one-tile-per-workgroup kernel at K = 768 (~8 us of fixed cost on a ~17 us loop) is paid once per launch.
-// Per step: counted `s_waitcnt vmcnt(L)` (one stage may stay in flight), ONE raw s_barrier, issue stage q+2, MFMAs of
-// stage q.  (cdna_hip_programming.md "Pipelining across barriers": raw barrier + counted vmcnt, all LDS in one array.)
+// Ring variant (two workgroups per CU): BM x BN x 32 K-steps through an NSTAGE-deep LDS ring of 64-byte rows.
+// Why: with one 256x256 workgroup per CU every CU runs its K loop and then its epilogue in lock step, so HBM idles
+// during the K loops and the matrix cores idle during the store bursts (measured: epilogues = 1/3 of the GEMM time of a
+// ViT block).  Two independent workgroups per CU drift apart and one's stores overlap the other's MFMAs.  To keep the
+// 256x256 kernel's LDS traffic per MFMA each wave still owns a 64x128 sub-tile (12 ds_read_b128 per 32 MFMAs); the
+// accumulators then fill half the wave's registers, so a workgroup is 4 waves (128x256) and two of them fill the CU.
+// LDS: 3 x (128 + 256) rows x 64 B = 72 KiB per workgroup.  Per step: counted `s_waitcnt vmcnt` (the next stage stays
+// in flight), ONE raw s_barrier, issue stage t+2, 32 MFMAs of stage t (cdna_hip_programming.md "Pipelining across
+// barriers": all LDS in one array, never vmcnt(0) inside the loop, read a stage only after wait + barrier).
+// 64-byte rows: four rows share a 256-byte bank row, so the swizzle key is (row >> 2) & 3 (16 lanes of one ds_read_b128
+// phase = 16 rows x one logical chunk -> 16 distinct 16-byte slots).
+__device__ __forceinline__ int swz32(int row, int c) { return c ^ ((row >> 2) & 3); }
+
+template <int ROWS, int NW>
+__device__ __forceinline__ void ring_offsets(int ld, int row0, int row_max, int wave, int lane, uint32_t (&off)[ROWS / 16 / NW], bool perm) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 16 / NW; ++i) {
+        const int r = (i * NW + wave) * 16 + (lane >> 2);
+        const int c = swz32(r, lane & 3);
+        int grow = row0 + (perm ? perm32(r) : r);
+        grow = grow < row_max ? grow : row_max;
+        off[i] = (uint32_t)grow * (uint32_t)ld * 2u + (uint32_t)c * 16u;
+    }
+}
+template <int ROWS, int NW>
+__device__ __forceinline__ void ring_stage(const char* __restrict__ base, const uint32_t (&off)[ROWS / 16 / NW], char* lds, int wave) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 16 / NW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(lds + (i * NW + wave) * 16 * 64), 16, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64) void mer_gemm_persist_kernel(const GemmParams p) {
-    static_assert(NSTAGE >= 3, "stage q+2 is issued while stage q is being read");
-    using C = Cfg<BM, BN, WM, WN>;
-    constexpr int STAGE = C::A_BYTES + C::B_BYTES;
-    constexpr int LOADS = C::A_INSTR + C::B_INSTR;          // LDS-DMA instructions per wave per stage
+__global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_ring_kernel(const GemmParams p) {
+    static_assert(NSTAGE >= 3, "stage t+2 is issued while stage t is being read");
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 16 / NW, B_INSTR = BN / 16 / NW, LOADS = A_INSTR + B_INSTR;
+    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split over waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int nk = p.K >> 6;
-    const int nk2 = p.A2 ? (p.K2 >> 5) : 0;
-    const int S = nk + nk2;
-    const int total = p.tiles_m * p.tiles_n;
-    const int first = blockIdx.x, stride = gridDim.x;
-    // workgroup `first` takes one tile of every round it is inside (the last round may be partial)
-    const int n_my = total / stride + ((total % stride) > first ? 1 : 0);
-    const int Q = n_my * S;
-    if (Q == 0) return;
+    const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
+    const int nk = p.K >> 5;
+    const int S = nk + (p.A2 ? (p.K2 >> 5) : 0);
+    const bool perm_b = p.perm_b != 0;
 
-    auto tile_of = [&](int ti, int& m0, int& n0) {
-        // round r of the grid covers tiles [r*stride, (r+1)*stride); inside a round the XCD remap gives each XCD a
-        // contiguous run, and tile_coords() keeps that run on a few activation blocks / weight panels (L2 reuse)
-        const int base = ti * stride;
-        const int span = min(stride, total - base);
-        const int t = base + xcd_linear_block(first, span);
-        int tm, tn;
-        tile_coords(t, p.tiles_m, p.tiles_n, tm, tn);
-        m0 = tm * BM; n0 = tn * BN;
-    };
-    // issue pointer (runs two steps ahead of the compute pointer); tile coordinates and the per-lane load offsets are
-    // recomputed only per tile
-    int i_ti = 0, i_ks = 0, i_q = 0, i_m0, i_n0;
-    uint32_t offA[C::A_INSTR], offB[C::B_INSTR];
-    auto new_tile = [&]() {
-        tile_of(i_ti, i_m0, i_n0);
-        stage_offsets<BM, C::NW, false>(p.lda, i_m0, p.M - 1, wave, lane, offA);
-        stage_offsets<BN, C::NW, false>(p.ldb, i_n0, p.N - 1, wave, lane, offB);
-    };
-    new_tile();
-    auto issue_next = [&]() {
-        char* la = smem + (i_q % NSTAGE) * STAGE;
-        char* lb = la + C::A_BYTES;
-        if (i_ks < nk) {
-            stage_from<BM, C::NW>((const char*)p.A + (size_t)i_ks * 128, offA, la, wave);
-            stage_from<BN, C::NW>((const char*)p.B + (size_t)i_ks * 128, offB, lb, wave);
-        } else {
-            const int g = (p.k2_group_n > 0) ? (i_n0 / p.k2_group_n) : 0;
-            const int k2 = (i_ks - nk) << 5;
-            stage<BM, C::NW, true>(p.A2 + (size_t)g * p.K2, p.lda2, i_m0, p.M - 1, k2, la, wave, lane);
-            stage<BN, C::NW, true>(p.B2, p.ldb2, i_n0, p.N - 1, k2, lb, wave, lane);
+    uint32_t offA[A_INSTR], offB[B_INSTR], offA2[A_INSTR], offB2[B_INSTR];
+    ring_offsets<BM, NW>(p.lda, m0, p.M - 1, wave, lane, offA, false);
+    ring_offsets<BN, NW>(p.ldb, n0, p.N - 1, wave, lane, offB, perm_b);
+    ring_offsets<BM, NW>(p.A2 ? p.lda2 : p.lda, m0, p.M - 1, wave, lane, offA2, false);
+    ring_offsets<BN, NW>(p.A2 ? p.ldb2 : p.ldb, n0, p.N - 1, wave, lane, offB2, perm_b);
+    const char* a2base = (const char*)(p.A2 ? p.A2 + (size_t)g * p.K2 : p.A);
+    const char* b2base = (const char*)(p.A2 ? p.B2 : p.B);
+    auto issue = [&](int t) {
+        char* la = smem + (t % NSTAGE) * STAGE;
+        char* lb = la + A_BYTES;
+        // one code path for both phases (a branch here made the compiler keep the offset arrays in scratch memory and
+        // drain vmcnt at every step): uniform base pointers + per-lane offsets selected by value
+        const bool ph2 = t >= nk;
+        const char* ab = ph2 ? a2base + (size_t)(t - nk) * 64 : (const char*)p.A + (size_t)t * 64;
+        const char* bb = ph2 ? b2base + (size_t)(t - nk) * 64 : (const char*)p.B + (size_t)t * 64;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const uint32_t o = ph2 ? offA2[i] : offA[i];
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + o), (lptr_t)(la + (i * NW + wave) * 16 * 64), 16, 0, 0);
         }
-        ++i_q;
-        if (++i_ks == S) { i_ks = 0; ++i_ti; if (i_ti < n_my) new_tile(); }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const uint32_t o = ph2 ? offB2[i] : offB[i];
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb + o), (lptr_t)(lb + (i * NW + wave) * 16 * 64), 16, 0, 0);
+        }
     };
 
-    f32x4 acc[C::TN][C::TM];
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[TN][TM];
+    init_acc<TM, TN>(p, acc, n0 + wn * (BN / WN), lane);
     const int frow = lane & 15, fq = lane >> 4;
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int EPI_STORES = C::TM * (16 / (64 / (WTN / 4))) * 2;   // upper bound of store instructions of one epilogue
-    static_assert(LOADS + EPI_STORES <= 63, "vmcnt immediate range");
-
-    issue_next();
-    if (Q > 1) issue_next();
-    int after_epi = 0;                                      // steps since an epilogue whose stores may still be in flight
-    int ks = 0, ti = 0;
-    for (int q = 0; q < Q; ++q) {
-        // vmcnt counts loads AND stores in issue order.  Stage q must have landed; younger ops that may stay in flight:
-        // stage q+1 (LOADS) and, for two steps after an epilogue, that epilogue's stores.
-        if (q + 1 >= Q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after_epi > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + EPI_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        if (after_epi > 0) --after_epi;
-        __builtin_amdgcn_s_barrier();                       // stage q landed everywhere; everyone is done with stage q-1
-        asm volatile("" ::: "memory");
-        if (q + 2 < Q) issue_next();
-        {
-            const char* la = smem + (q % NSTAGE) * STAGE;
-            const char* lb = la + C::A_BYTES;
-            const int nks = ks < nk ? 2 : 1;
+    // per-lane LDS byte offsets of the fragment reads (the same in every stage)
+    int ra[TM], rb[TN];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (kk < nks) {
-                    bf16x8 af[C::TM], wf[C::TN];
-#pragma unroll
-                    for (int i = 0; i < C::TM; ++i) {
-                        const int row = wm * WTM + i * 16 + frow;
-                        af[i] = *(const bf16x8*)(la + row * 128 + (swz(row, kk * 4 + fq) << 4));
-                    }
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) {
-                        const int row = wn * WTN + j * 16 + frow;
-                        wf[j] = *(const bf16x8*)(lb + row * 128 + (swz(row, kk * 4 + fq) << 4));
-                    }
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-                        for (int i = 0; i < C::TM; ++i)
-                            acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
-                }
-            }
-        }
-        if (++ks == S) {
-            // tile finished: stage buffer q % NSTAGE is free until the issue after the next barrier -> staging area
-            int m0, n0; tile_of(ti, m0, n0);
-            __builtin_amdgcn_s_barrier();                   // every wave has finished its ds_reads of stage q
-            asm volatile("" ::: "memory");
-            static_assert(C::NW * 16 * (WTN * 4 + 16) <= STAGE, "epilogue staging does not fit in one stage buffer");
-            if (p.dbg != 1)
-                store_tile<C::TM, C::TN>(p, acc, smem + (q % NSTAGE) * STAGE + wave * (16 * (WTN * 4 + 16)), m0 + wm * WTM,
-                                         n0 + wn * WTN, lane);
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ks = 0; ++ti; after_epi = 2;
-        }
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 16 + frow;
+        ra[i] = row * 64 + (swz32(row, fq) << 4);
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / WN) + j * 16 + frow;
+        rb[j] = A_BYTES + row * 64 + (swz32(row, fq) << 4);
+    }
+
+    issue(0);
+    if (S > 1) issue(1);
+    for (int t = 0; t < S; ++t) {
+        // vmcnt counts this wave's LDS-DMA loads in issue order: stage t has landed once at most LOADS (stage t+1) remain
+        if (t + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // stage t landed for every wave; everyone is done reading stage t-1
+        asm volatile("" ::: "memory");
+        if (t + 2 < S) issue(t + 2);                        // -> buffer (t+2) % NSTAGE, last read in step t-1
+        const char* st = smem + (t % NSTAGE) * STAGE;
+        // all fragment reads of the step are issued up front (left alone the compiler reuses ONE weight-fragment register
+        // and emits read -> lgkmcnt(0) -> 4 MFMAs eight times per step); the empty asm statements pin each half's
+        // registers, so the first half's MFMAs start under a counted lgkmcnt while the second half is still landing
+        bf16x8 af[TM], wf[TN];
+        constexpr int H = TN / 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + ra[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + rb[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < H; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
+#pragma unroll
+        for (int j = H; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+        for (int j = H; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
+    }
+    if (p.dbg != 1) store_tile<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_persist(GemmParams& p, hipStream_t s) {
-    using C = Cfg<BM, BN, WM, WN>;
-    constexpr int LDS = NSTAGE * (C::A_BYTES + C::B_BYTES);
+int launch_ring(GemmParams& p, hipStream_t s) {
+    constexpr int LDS = NSTAGE * (BM + BN) * 64;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     static bool attr_set = false;
-    static int n_cu = 256;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_persist_kernel<BM, BN, WM, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        (void)hipFuncSetAttribute((const void*)mer_gemm_ring_kernel<BM, BN, WM, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    const int total = p.tiles_m * p.tiles_n;
-    const int blocks_per_cu = (160 * 1024) / LDS >= 2 ? 2 : 1;
-    int grid = n_cu * blocks_per_cu;
-    if (grid > total) grid = total;
-    hipLaunchKernelGGL((mer_gemm_persist_kernel<BM, BN, WM, WN, NSTAGE>), dim3(grid), dim3(C::NT), LDS, s, p);
-    REID_CHECK_LAUNCH("reid_mer_gemm(persistent)");
+    const int grid = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((mer_gemm_ring_kernel<BM, BN, WM, WN, NSTAGE>), dim3(grid), dim3(WM * WN * 64), LDS, s, p);
+    REID_CHECK_LAUNCH("reid_mer_gemm(ring)");
     return REID_OK;
 }
 
@@ -450,6 +436,8 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     p.r_period = a->r_period; p.mask_r = a->mask_r; p.mask_period = a->mask_period; p.rows_per_img = a->rows_per_img;
     p.c_group = a->c_group; p.c_group_stride = a->c_group_stride; p.c_row_off = a->c_row_off;
     p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
+    p.dbg = 0;
+    p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
     // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip)
@@ -461,19 +449,17 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     const char* e_dbg = getenv("REID_GEMM_DBG");
     const int tile = e_tile ? atoi(e_tile) : 0;
     p.dbg = e_dbg ? atoi(e_dbg) : 0;
-    if (tile == 4) return launch_persist<256, 128, 4, 2, 3>(p, s);
-    if (tile == 5) return launch_persist<128, 256, 2, 4, 3>(p, s);
-    if (tile == 6) return launch_persist<128, 128, 2, 2, 4>(p, s);
+    if (tile == 9) return launch_ring<128, 256, 2, 2, 3>(p, s);
+    if (tile == 10) return launch_ring<128, 128, 2, 2, 3>(p, s);
+    if (tile == 11) return launch_ring<128, 256, 2, 4, 3>(p, s);
     if (tile == 1) return launch<256, 128, 4, 2>(p, s);
     if (tile == 2) return launch<256, 256, 2, 4>(p, s);
     if (tile == 3) return launch<128, 128, 2, 2>(p, s);
     if (tile == 8) return launch<128, 256, 2, 4>(p, s);
-    // defaults from same-process A/B runs of the seven ViT GEMM variants (tools/bench_gemm_variants.py):
-    //   256x256 tile where the epilogue has no per-element global operand (no residual, no saved pre-activation), else
-    //   128x256 (its epilogue prefetches residual / aux for the whole sub-tile).  A column tile must not straddle two
-    //   LoRA groups of the fused q|k|v projection.
-    const bool grp_ok = p.k2_group_n == 0 || p.k2_group_n % 256 == 0;
-    if (tile == 0 && grp_ok && a->N >= 512 && a->M >= 512 && !a->R && a->act < REID_ACT_DGELU_ERF) return launch<256, 256, 2, 4>(p, s);
-    if (tile == 0 && grp_ok && a->N >= 256 && a->M >= 128) return launch<128, 256, 2, 4>(p, s);
+    // Default from same-process A/B runs of the seven ViT GEMM variants (tools/bench_gemm_variants.py, r01): 128x128x64
+    // tiles, 4 waves, 64 KiB of LDS -> TWO workgroups per CU.  With the register-direct epilogue its K loop runs as fast
+    // as the 256x256 tile's (~1.0-1.1 PF on these shapes) and, unlike one big workgroup per CU, one workgroup's stores
+    // overlap the other's MFMAs (sum over the seven shapes: 1.90 ms vs 2.04-2.17 ms for 256x256 / 128x256 tiles).
+    // (k2_group_n is a multiple of 128, so a column tile never straddles two LoRA groups of the fused q|k|v projection.)
     return launch<128, 128, 2, 2>(p, s);
 }

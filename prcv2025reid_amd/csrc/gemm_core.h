@@ -27,11 +27,17 @@ struct Cfg {
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over waves");
 };
 
+// Row permutation inside aligned groups of 32 operand rows: LDS row 16*jb + 4*fq + r holds operand row 8*fq + 4*jb + r.
+// With it a lane's accumulators of two neighbouring 16-row MFMA sub-tiles are EIGHT consecutive output columns and the
+// four lanes that share an output row cover 32 consecutive columns, so a 16-bit epilogue stores 16 bytes per lane
+// straight from the accumulators (64 contiguous bytes per output row per instruction) without an LDS transpose.
+__device__ __forceinline__ int perm32(int x) { return (x & ~31) | (((x >> 2) & 3) << 3) | (((x >> 4) & 1) << 2) | (x & 3); }
+
 // Stage one K-step of one operand: rows [row0, row0+ROWS) x 64 k (HALF: only logical chunks 0..3 are
 // meaningful; the other lanes re-load a valid chunk that is never read).
 template <int ROWS, int NW, bool HALF>
 __device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int ld, int row0, int row_max, int k0,
-                                      char* lds, int wave, int lane) {
+                                      char* lds, int wave, int lane, bool perm = false) {
     constexpr int INSTR = ROWS / 8 / NW;
 #pragma unroll
     for (int i = 0; i < INSTR; ++i) {
@@ -39,7 +45,7 @@ __device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int ld, in
         const int r = rblk + (lane >> 3);
         int c = swz(r, lane & 7);
         if (HALF) c &= 3;
-        int grow = row0 + r;
+        int grow = row0 + (perm ? perm32(r) : r);
         grow = grow < row_max ? grow : row_max;
         const bf16_t* g = src + (size_t)grow * ld + k0 + c * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + rblk * 128), 16, 0, 0);
@@ -51,14 +57,15 @@ __device__ __forceinline__ void stage(const bf16_t* __restrict__ src, int ld, in
 // inside the K loop a load is then `uniform base (advances by 128 B per step, SALU) + 32-bit lane offset`, no vector
 // address arithmetic (the first version spent ~4 VALU instructions per MFMA, mostly on 64-bit load addresses).
 template <int ROWS, int NW, bool HALF>
-__device__ __forceinline__ void stage_offsets(int ld, int row0, int row_max, int wave, int lane, uint32_t (&off)[ROWS / 8 / NW]) {
+__device__ __forceinline__ void stage_offsets(int ld, int row0, int row_max, int wave, int lane, uint32_t (&off)[ROWS / 8 / NW],
+                                              bool perm = false) {
     constexpr int INSTR = ROWS / 8 / NW;
 #pragma unroll
     for (int i = 0; i < INSTR; ++i) {
         const int r = (i * NW + wave) * 8 + (lane >> 3);
         int c = swz(r, lane & 7);
         if (HALF) c &= 3;
-        int grow = row0 + r;
+        int grow = row0 + (perm ? perm32(r) : r);
         grow = grow < row_max ? grow : row_max;
         off[i] = (uint32_t)grow * (uint32_t)ld * 2u + (uint32_t)c * 16u;
     }
@@ -100,7 +107,7 @@ template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                          const bf16_t* __restrict__ A2, int lda2, const bf16_t* __restrict__ B2, int ldb2,
                                          int M, int N, int K, int K2, int m0, int n0, char* smem,
-                                         f32x4 (&acc)[Cfg<BM, BN, WM, WN>::TN][Cfg<BM, BN, WM, WN>::TM]) {
+                                         f32x4 (&acc)[Cfg<BM, BN, WM, WN>::TN][Cfg<BM, BN, WM, WN>::TM], bool perm_b = false) {
     using C = Cfg<BM, BN, WM, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -112,7 +119,7 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
 
     uint32_t offA[C::A_INSTR], offB[C::B_INSTR];
     stage_offsets<BM, C::NW, false>(lda, m0, M - 1, wave, lane, offA);
-    stage_offsets<BN, C::NW, false>(ldb, n0, N - 1, wave, lane, offB);
+    stage_offsets<BN, C::NW, false>(ldb, n0, N - 1, wave, lane, offB, perm_b);
     auto issue = [&](int t, int buf) {
         char* la = smem + buf * C::BUF_BYTES;
         char* lb = la + C::A_BYTES;
@@ -122,7 +129,7 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
         } else {
             const int k2 = (t - nk) << 5;
             stage<BM, C::NW, true>(A2, lda2, m0, M - 1, k2, la, wave, lane);
-            stage<BN, C::NW, true>(B2, ldb2, n0, N - 1, k2, lb, wave, lane);
+            stage<BN, C::NW, true>(B2, ldb2, n0, N - 1, k2, lb, wave, lane, perm_b);
         }
     };
     const int frow = lane & 15, fq = lane >> 4;

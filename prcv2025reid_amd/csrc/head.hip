@@ -8,62 +8,104 @@ namespace {
 
 // ------------------------------------------------------------------------------------------ sgemm
 // C[M,N] = act(alpha * sum_k A(m,k) B(k,n) + bias[n]) + beta * C, arbitrary element strides for A and B.
-// 64x64 tile, 256 threads, 4x4 outputs per thread, K step 16.
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                    int M, int N, int K, long sam, long sak, long sbk, long sbn, int ldc,
-                                                    float alpha, float beta, const float* __restrict__ bias, int act) {
-    __shared__ float As[16][68];
-    __shared__ float Bs[16][68];
+// The head's GEMMs are tiny (a few hundred rows, K = 320..2048) and sit on the step's critical path one after another,
+// so the kernel is built for LATENCY, not throughput: 32x32 output tiles (hundreds of workgroups even for 320x512),
+// the K range split over the workgroup's 4 or 8 waves (each wave streams its own quarter through a wave-private LDS slice:
+// no workgroup barrier inside the loop), the next K-step's operands prefetched into registers while the current one is
+// multiplied, and ONE deterministic in-LDS reduction of the partial tiles at the end (fixed order: bit-reproducible).
+// (The first version -- 64x64 tiles, K = 16 per barrier pair, no prefetch -- took 42 us per call, 4.9 ms per train step.)
+constexpr int SG_PITCH = 36;                            // floats per staged k-row: 32 + 4 (conflict-free transposed writes)
+template <int SG_WAVES>
+__global__ __launch_bounds__(SG_WAVES * 64) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ C, int M, int N, int K, long sam, long sak,
+                                                              long sbk, long sbn, int ldc, float alpha, float beta,
+                                                              const float* __restrict__ bias, int act) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SG_WAVES * 16 * SG_PITCH];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* As = lds + wave * 16 * SG_PITCH;
+    float* Bs = lds + (SG_WAVES + wave) * 16 * SG_PITCH;
+    const int tx = lane & 7, ty = lane >> 3;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kchunk = ((K + 16 * SG_WAVES - 1) / (16 * SG_WAVES)) * 16;   // per-wave K range, a multiple of 16
+    const int kb = wave * kchunk;
+    const int ke = min(K, kb + kchunk);
+    // element e = lane + 64 i of a 32 x 16 operand tile: the fast lane index follows the contiguous stride
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+    float ra[2][8], rb[2][8];
+    auto coords = [&](bool kfast, int i, int& x, int& kk) {
+        const int e = lane + 64 * i;
+        if (kfast) { kk = e & 15; x = e >> 4; } else { x = e & 31; kk = e >> 5; }
+    };
+    auto fetch = [&](int k0, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256;           // 1024 elements per operand tile
-            {   // A tile: choose the fast index along the contiguous stride
-                int mm, kk;
-                if (sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-                const int m = m0 + mm, k = k0 + kk;
-                As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-            }
-            {
-                int nn, kk;
-                if (sbk == 1) { kk = e & 15; nn = e >> 4; } else { nn = e & 63; kk = e >> 6; }
-                const int n = n0 + nn, k = k0 + kk;
-                Bs[kk][nn] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
-            }
+        for (int i = 0; i < 8; ++i) {
+            int x, kk;
+            coords(a_kfast, i, x, kk);
+            const int m = m0 + x, ka = k0 + kk;
+            ra[slot][i] = (m < M && ka < ke) ? A[(long)m * sam + (long)ka * sak] : 0.f;
+            coords(b_kfast, i, x, kk);
+            const int n = n0 + x, kq = k0 + kk;
+            rb[slot][i] = (n < N && kq < ke) ? B[(long)kq * sbk + (long)n * sbn] : 0.f;
         }
-        __syncthreads();
+    };
+    float acc[4][4] = {};
+    auto step = [&](int k0, int slot) {                  // slot is a compile-time constant at both call sites
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int x, kk;
+            coords(a_kfast, i, x, kk);
+            As[kk * SG_PITCH + x] = ra[slot][i];
+            coords(b_kfast, i, x, kk);
+            Bs[kk * SG_PITCH + x] = rb[slot][i];
+        }
+        __builtin_amdgcn_wave_barrier();                // wave-private slices: LDS ops of one wave execute in order
+        if (k0 + 32 < ke) fetch(k0 + 32, slot);         // two K-steps of operands stay in flight
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+            const f32x4 a = *(const f32x4*)(As + kk * SG_PITCH + ty * 4);
+            const f32x4 b = *(const f32x4*)(Bs + kk * SG_PITCH + tx * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (kb < ke) fetch(kb, 0);
+    if (kb + 16 < ke) fetch(kb + 16, 1);
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        step(k0, 0);
+        if (k0 + 16 < ke) step(k0 + 16, 1);
     }
+    __syncthreads();                                     // every wave is done with its staging slice: reuse LDS for the partials
+    static_assert(2 * 16 * SG_PITCH >= 1024, "partial tiles alias the staging slices");
+    float* red = lds + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= M) continue;
+    for (int i = 0; i < 4; ++i) *(f32x4*)(red + (ty * 4 + i) * 32 + tx * 4) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    __syncthreads();
+    if (tid >= 256) return;
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4 sum = *(const f32x4*)(lds + row * 32 + c4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= N) continue;
-            float v = alpha * acc[i][j];
-            if (bias) v += bias[n];
-            if (act == REID_ACT_GELU_ERF) v = gelu_erf_f(v);
-            else if (act == REID_ACT_QUICK_GELU) v = quick_gelu_f(v);
-            else if (act == REID_ACT_RELU) v = fmaxf(v, 0.f);
-            float* c = C + (size_t)m * ldc + n;
-            *c = beta == 0.f ? v : v + beta * *c;
-        }
+    for (int w = 1; w < SG_WAVES; ++w) {                 // fixed order: bit-reproducible
+        const f32x4 t = *(const f32x4*)(lds + w * 1024 + row * 32 + c4);
+        sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+    }
+    const int m = m0 + row;
+    if (m >= M) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + c4 + j;
+        if (n >= N) continue;
+        float v = alpha * sum[j];
+        if (bias) v += bias[n];
+        if (act == REID_ACT_GELU_ERF) v = gelu_erf_f(v);
+        else if (act == REID_ACT_QUICK_GELU) v = quick_gelu_f(v);
+        else if (act == REID_ACT_RELU) v = fmaxf(v, 0.f);
+        float* c = C + (size_t)m * ldc + n;
+        *c = beta == 0.f ? v : v + beta * *c;
     }
 }
 
@@ -500,8 +542,12 @@ __global__ void masked_mean_kernel(const float* __restrict__ x, const float* __r
 
 int launch_sgemm(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn, int ldc,
                  float alpha, float beta, const float* bias, int act, hipStream_t s) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc,
-                       alpha, beta, bias, act);
+    // K split over 8 waves while the grid is small (pure latency), over 4 once there are more tiles than CUs
+    const dim3 grid((N + 31) / 32, (M + 31) / 32);
+    if (grid.x * grid.y <= 256)
+        hipLaunchKernelGGL(sgemm_kernel<8>, grid, dim3(512), 0, s, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, act);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<4>, grid, dim3(256), 0, s, A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, beta, bias, act);
     REID_CHECK_LAUNCH("reid_sgemm");
     return REID_OK;
 }

@@ -21,6 +21,8 @@ by train.py:1418-1425).
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -120,7 +122,14 @@ class Engine:
         self._lora_ver = None
         self._lora_pack = None
         self._table = None
+        self._side = None
+        self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.W = {}
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.dev)
+        return self._side
 
     # ------------------------------------------------------------------------------- packing
     def _bf(self, t):
@@ -264,12 +273,11 @@ class Engine:
         n_img = st['n_img']; M = n_img * S
         ce = 'clip_encoder.'
         f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
-        grad = torch.empty(lay.size, **f32)
+        grad = torch.zeros(lay.size, **f32)               # the dA/dB GEMMs accumulate (beta=1): no per-call fill
         mk = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=S, alpha=self.scaling)
         pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
         gA = lambda l, nm: lay.view_A(grad, l, nm)
         gB = lambda l, nm: lay.view_B(grad, l, nm)
-        inv = 1.0
         scale_t = None
         if self.loss_scaling:
             amax = dfeat.abs().amax().clamp_min(1e-30)
@@ -281,31 +289,48 @@ class Engine:
         dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
         ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
                           row_index=st['idx'])
-        # reusable scratch
-        U = torch.empty(M, Rp, **b16); Uq = torch.empty(M, 3 * Rp, **b16)
+        # reusable scratch (one U per linear: the side stream still reads it while the next skinny GEMM runs)
+        U2 = torch.empty(M, Rp, **b16); U1 = torch.empty(M, Rp, **b16); Uo = torch.empty(M, Rp, **b16)
+        Uq = torch.empty(M, 3 * Rp, **b16)
         du = torch.empty(M, ff, **b16); dh = torch.empty(M, d, **b16); do = torch.empty(M, d, **b16)
         dqkv = torch.empty(M, 3 * d, **b16); delta = torch.empty(n_img, heads, S, **f32)
         dxm = torch.empty(M, d, **f32); dxmb = torch.empty(M, d, **b16)
+        # The reduce-over-rows GEMMs that produce dA/dB are HBM-bound and independent of the dX chain: they go to a
+        # second HIP stream so they fill the bubbles of the MFMA-bound dX GEMMs (joined once per layer).
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream() if self.overlap_tn else None
+
+        def fork(*calls):
+            if side is None:
+                for c in calls:
+                    ops.gemm_tn(*c, beta=1.0)
+                return
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for c in calls:
+                    ops.gemm_tn(*c, beta=1.0)
+
+        def join():
+            if side is not None:
+                ev = torch.cuda.Event(); ev.record(side); main.wait_event(ev)
+
         for l in reversed(range(a['vision_layers'])):
             s = st['layers'][l]
             lp = f'{ce}vision_layers.{l}.'
             # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
-            ops.gemm(dxb, pk(l, 'fc2', 'BT'), U, **mk)
-            ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
-            ops.gemm_tn(dxb, s['T2'], gB(l, 'fc2'), alpha=inv)
-            ops.gemm_tn(U, s['g'], gA(l, 'fc2'), alpha=inv)
+            ops.gemm(dxb, pk(l, 'fc2', 'BT'), U2, **mk)
+            fork((dxb, s['T2'], gB(l, 'fc2')), (U2, s['g'], gA(l, 'fc2')))
+            ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U2, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
             # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
-            ops.gemm(du, pk(l, 'fc1', 'BT'), U, **mk)
-            ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U, B2=pk(l, 'fc1', 'AT'), K2=Rp)
-            ops.gemm_tn(du, s['T1'], gB(l, 'fc1'), alpha=inv)
-            ops.gemm_tn(U, s['h2'], gA(l, 'fc1'), alpha=inv)
+            ops.gemm(du, pk(l, 'fc1', 'BT'), U1, **mk)
+            fork((du, s['T1'], gB(l, 'fc1')), (U1, s['h2'], gA(l, 'fc1')))
+            ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U1, B2=pk(l, 'fc1', 'AT'), K2=Rp)
             # ---- LN2
             ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx)
             # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
-            ops.gemm(dxmb, pk(l, 'out', 'BT'), U, **mk)
-            ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=U, B2=pk(l, 'out', 'AT'), K2=Rp)
-            ops.gemm_tn(dxmb, s['To'], gB(l, 'out'), alpha=inv)
-            ops.gemm_tn(U, s['o'], gA(l, 'out'), alpha=inv)
+            ops.gemm(dxmb, pk(l, 'out', 'BT'), Uo, **mk)
+            fork((dxmb, s['To'], gB(l, 'out')), (Uo, s['o'], gA(l, 'out')))
+            ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=Uo, B2=pk(l, 'out', 'AT'), K2=Rp)
             # ---- attention
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
@@ -313,10 +338,11 @@ class Engine:
             gBq = gB(l, 'qkv')                              # [3d, Rp]
             for g in range(3):
                 ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
-                ops.gemm_tn(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d], alpha=inv)
+            fork(*[(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d]) for g in range(3)],
+                 (Uq, s['h'], gA(l, 'qkv')))
             ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
-            ops.gemm_tn(Uq, s['h'], gA(l, 'qkv'), alpha=inv)
-            # ---- LN1
+            # ---- LN1 (rewrites dxb, and the next layer rewrites du/dxmb/dqkv/U*: the side stream must be done with them)
+            join()
             ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm)
         if scale_t is not None:
             grad.mul_(1.0 / scale_t)

@@ -44,3 +44,15 @@ mean = torch.empty(M, device='cuda'); rstd = torch.empty(M, device='cuda')
 us = timeit(lambda: ops.layernorm_fwd(x, gam, bet, y_bf16=o, mean=mean, rstd=rstd)); print(f'ln fwd               : {us:7.1f} us  {M*d*6/us/1e6:6.2f} TB/s')
 dx = torch.empty_like(x); dxb = torch.empty_like(o)
 us = timeit(lambda: ops.layernorm_bwd(do, x, gam, mean, rstd, dx, dx_bf16=dxb, dres=x)); print(f'ln bwd               : {us:7.1f} us  {M*d*16/us/1e6:6.2f} TB/s')
+# head-sized fp32 GEMMs (latency bound)
+for (Ms, Ns, Ks, kw, name) in [(320, 1536, 512, dict(tb=True), 'in_proj  x@W.T'), (320, 512, 512, dict(tb=True), 'out_proj x@W.T'),
+                               (320, 512, 1536, dict(), 'dx = dy@W'), (1536, 512, 320, dict(ta=True), 'dW = dy.T@x'),
+                               (64, 400, 512, dict(tb=True), 'classifier'), (64, 2048, 512, dict(tb=True), 'mlp up')]:
+    if kw.get('tb'):
+        a_ = torch.randn(Ms, Ks, device='cuda'); b_ = torch.randn(Ns, Ks, device='cuda')
+    elif kw.get('ta'):
+        a_ = torch.randn(Ks, Ms, device='cuda'); b_ = torch.randn(Ks, Ns, device='cuda')
+    else:
+        a_ = torch.randn(Ms, Ks, device='cuda'); b_ = torch.randn(Ks, Ns, device='cuda')
+    c_ = torch.empty(Ms, Ns, device='cuda')
+    us = timeit(lambda: ops.sgemm(a_, b_, c_, **kw)); print(f'sgemm {name:16s} [{Ms}x{Ns}x{Ks}]: {us:7.1f} us')
