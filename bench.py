@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-retrieval', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'])
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for rehearsals')
     ap.add_argument('--compute-dtype', default=None, choices=[None, 'bf16', 'f16'])
     return ap.parse_args()
@@ -168,18 +169,28 @@ def main():
     tok = model.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
     tokens = {k: v.to(dev) for k, v in tok.items()}     # pre-tokenised, resident in HBM
     labels = batch['person_id'].to(dev)
-    params = [{'params': [p for p in g['params'] if p.requires_grad], 'lr': g['lr']} for g in model.get_learnable_params()]
-    params = [g for g in params if g['params']]
-    opt = torch.optim.AdamW(params, weight_decay=1e-4)
+    groups = [dict(params=[p for p in g['params'] if p.requires_grad], lr=g['lr'], name=g['name'])
+              for g in model.get_learnable_params()]
+    groups = [g for g in groups if g['params']]
+    if args.optimizer == 'fused':
+        # the reference's step (train.py:975-1047): sanitise, adaptive clip, AdamW -- three fused launches, no host sync
+        from prcv2025reid_amd.trainer import FusedAdamW, StepDriver
+        opt = FusedAdamW(groups, weight_decay=1e-4)
+        driver = StepDriver(dp, opt, accum_steps=1, adaptive_clip=True, dp=dp)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = dp.forward(images=images, texts=tokens, modality_masks=masks)
-        L = dp.compute_loss(out, labels)
-        L['total_loss'].backward()
-        dp.reduce_grads()
-        opt.step()
-        return L
+        def step():
+            return driver.step(images, tokens, masks, labels)
+    else:
+        opt = torch.optim.AdamW(groups, weight_decay=1e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = dp.forward(images=images, texts=tokens, modality_masks=masks)
+            L = dp.compute_loss(out, labels)
+            L['total_loss'].backward()
+            dp.reduce_grads()
+            opt.step()
+            return L
 
     log(f'model built, {args.warmup} warm-up steps')
     for _ in range(args.warmup):
@@ -226,7 +237,7 @@ def main():
             'dtype': model.compute_dtype, 'data': 'synthetic',
             'config': {'workload': f'P={P},K={K} per GPU, vis/nir/sk/cp 224x224 + text (T<=77), CLIP ViT-B/16 + text tower '
                                    f'random-init, MER-LoRA r={args.rank}, masks {"all-on" if args.mask_drop == 0 else args.mask_drop}, '
-                                   f'{C} ids, SDM+CE, fwd+bwd+AdamW (reference default trainable set)',
+                                   f'{C} ids, SDM+CE, fwd+bwd+grad sanitise/clip+AdamW (reference default trainable set)',
                        'P': P, 'K': K, 'global_batch': world * B, 'lora_rank': args.rank, 'parallelism': f'dp{world}'},
             'model_tflops_per_gpu': value / world * FLOP_PER_INSTANCE / 1e12,
             'mfma_frac_whole_step': value / world * FLOP_PER_INSTANCE / 1e12 / PEAK_BF16_TFLOPS,

@@ -258,6 +258,34 @@ int reid_masked_mean(const float* x, const float* mask, float* out, int32_t B, i
 int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t D,
                      float eps, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step of the training driver: train.py:85-96 (_sanitize_grads),
+ * :975-1047 (gradient norm, adaptive / fixed clip, optimizer.step()) with torch.optim.AdamW semantics
+ * (decoupled weight decay, bias correction, no amsgrad), as three sync-free launches over a DEVICE table of
+ * reid_opt_entry records (one per trainable flat fp32 buffer, 16-byte aligned; g == NULL skips the entry):
+ *   reid_opt_sumsq  non-finite gradient entries := 0 in place; per-workgroup partial sums of g^2 and counts -> ws
+ *   reid_opt_clip   state[1] = ||g||_2 (fixed summation order), state[3] = max_norm, state[2] = clip coefficient
+ *                   min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_), state[4] = #non-finite;
+ *                   adaptive != 0: train.py:981-1001 -- when record != 0 the norm is appended to the history
+ *                   (state[5] = count, state[6..15] = last ten), max_norm = min(3, max(0.5, 1.15 * percentile70(last ten)))
+ *                   once more than ten norms were recorded, else 1.0; adaptive == 0: max_norm = fixed_max_norm
+ *   reid_opt_adamw  p, exp_avg, exp_avg_sq updated with gradient g * (*coef) (coef may be NULL = 1); step counts from 1;
+ *                   zero_grad != 0 clears g in the same pass (optimizer.zero_grad at the next accumulation window)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct reid_opt_entry {
+    float* p; float* g; float* exp_avg; float* exp_avg_sq;
+    int64_t n;
+    float lr, weight_decay;
+} reid_opt_entry;
+int32_t reid_opt_entry_bytes(void);
+int32_t reid_opt_ws_floats(int32_t n_entries);
+int32_t reid_opt_state_floats(void);
+int reid_opt_sumsq(const void* table, int32_t n_entries, float* ws, void* stream);
+int reid_opt_clip(const float* ws, int32_t n_entries, float* state, int32_t adaptive, float fixed_max_norm,
+                  int32_t record, void* stream);
+int reid_opt_adamw(const void* table, int32_t n_entries, const float* coef, float beta1, float beta2, float eps,
+                   int32_t step, int32_t zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

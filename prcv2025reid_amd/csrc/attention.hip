@@ -21,16 +21,24 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 1) & 7); }
 
-// stage rows [0, rows_pad) x 64 bf16 of one head (column offset col0 of a [*, ld] matrix) into a
-// swizzled [rows_pad][64] LDS image; rows >= S are zero.
-__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ base, int ld, int S, int rows_pad, char* lds, int tid,
-                                           int nthreads) {
-    for (int t = tid; t < rows_pad * 8; t += nthreads) {
-        const int row = t >> 3, pch = t & 7;
-        const int c = swz(row, pch);
-        uint4 v = {0u, 0u, 0u, 0u};
-        if (row < S) v = *(const uint4*)(base + (size_t)row * ld + c * 8);
-        *(uint4*)(lds + row * 128 + pch * 16) = v;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Stage rows [0, 32 NT) x 64 of one head (column offset already applied to `base`, row stride ld) into a swizzled
+// [32 NT][64] LDS image with 16-byte LDS-DMA: every wave issues its 4 wave-instructions (8 rows each) back to back, so
+// all of the head's bytes are in flight at once (the first version looped load -> LDS store per 16-byte chunk and paid
+// eight exposed HBM round trips per workgroup: ~16 of the ~22 us a workgroup lived).  The LDS image is lane-linear, the
+// swizzle is applied to the SOURCE chunk.  Rows >= S repeat row S-1 (finite values): every consumer masks them (padded
+// keys get probability 0, padded queries get P = 0 through lse = +inf), so no zero fill is needed.
+template <int NT>
+__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ base, int ld, int S, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rblk = (i * NT + wave) * 8;
+        const int row = rblk + (lane >> 3);
+        const int c = swz(row, lane & 7);
+        const int grow = row < S ? row : S - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)grow * ld + c * 8), (lptr_t)(lds + rblk * 128), 16, 0, 0);
     }
 }
 
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
     const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
-    stage_head(qb + d, p.ld, p.S, NT * 32, Ks, tid, NT * 64);
-    stage_head(qb + 2 * d, p.ld, p.S, NT * 32, Vs, tid, NT * 64);
+    stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);
+    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
 
     const int q0 = wave * 32;
     const int qi = q0 + (lane & 31);
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
     const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
-    stage_head(qb, p.ld, p.S, NT * 32, Qs, tid, NT * 64);
-    stage_head(gb, p.ldo, p.S, NT * 32, Gs, tid, NT * 64);
+    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane);
+    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane);
     for (int t = tid; t < NT * 32; t += NT * 64) {
         const size_t o = ((size_t)seq * p.heads + head) * p.S + t;
         rowc[t] = t < p.S ? -p.lse[o] * LOG2E : -INFINITY;          // exp2(s*c + rowc) = P; padded queries give 0
@@ -348,8 +356,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
     const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
-    stage_head(qb + d, p.ld, p.S, NT * 32, Ks, tid, NT * 64);
-    stage_head(qb + 2 * d, p.ld, p.S, NT * 32, Vs, tid, NT * 64);
+    stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);
+    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
     const int q0 = wave * 32;
     const int qi = q0 + (lane & 31);
     const int qrow = qi < p.S ? qi : p.S - 1;

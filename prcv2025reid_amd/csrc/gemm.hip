@@ -47,7 +47,7 @@ using namespace gemmcore;
 // bytes per output row per instruction, full 64-byte requests (an earlier version without the permutation stored 8-byte
 // pieces scattered over 16 rows and cost as much as the K loop at K = 768; the LDS-transposing version that replaced it
 // chained LDS write -> wait -> read -> store per 16 rows and ran at ~12 GB/s per CU).
-// Residual / saved-pre-activation operands are prefetched DEPTH row groups ahead (a register ring, indices static after
+// Residual / saved-pre-activation operands are prefetched RD pieces ahead (a register ring, indices static after
 // unrolling); all operand loads are unconditional with clamped addresses (no branch, no wait between them).
 template <int CW>
 struct Piece { float v[CW]; };
@@ -231,156 +231,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     if (p.dbg != 1) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Ring variant (two workgroups per CU): BM x BN x 32 K-steps through an NSTAGE-deep LDS ring of 64-byte rows.
-// Why: with one 256x256 workgroup per CU every CU runs its K loop and then its epilogue in lock step, so HBM idles
-// during the K loops and the matrix cores idle during the store bursts (measured: epilogues = 1/3 of the GEMM time of a
-// ViT block).  Two independent workgroups per CU drift apart and one's stores overlap the other's MFMAs.  To keep the
-// 256x256 kernel's LDS traffic per MFMA each wave still owns a 64x128 sub-tile (12 ds_read_b128 per 32 MFMAs); the
-// accumulators then fill half the wave's registers, so a workgroup is 4 waves (128x256) and two of them fill the CU.
-// LDS: 3 x (128 + 256) rows x 64 B = 72 KiB per workgroup.  Per step: counted `s_waitcnt vmcnt` (the next stage stays
-// in flight), ONE raw s_barrier, issue stage t+2, 32 MFMAs of stage t (cdna_hip_programming.md "Pipelining across
-// barriers": all LDS in one array, never vmcnt(0) inside the loop, read a stage only after wait + barrier).
-// 64-byte rows: four rows share a 256-byte bank row, so the swizzle key is (row >> 2) & 3 (16 lanes of one ds_read_b128
-// phase = 16 rows x one logical chunk -> 16 distinct 16-byte slots).
-__device__ __forceinline__ int swz32(int row, int c) { return c ^ ((row >> 2) & 3); }
-
-template <int ROWS, int NW>
-__device__ __forceinline__ void ring_offsets(int ld, int row0, int row_max, int wave, int lane, uint32_t (&off)[ROWS / 16 / NW], bool perm) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 16 / NW; ++i) {
-        const int r = (i * NW + wave) * 16 + (lane >> 2);
-        const int c = swz32(r, lane & 3);
-        int grow = row0 + (perm ? perm32(r) : r);
-        grow = grow < row_max ? grow : row_max;
-        off[i] = (uint32_t)grow * (uint32_t)ld * 2u + (uint32_t)c * 16u;
-    }
-}
-template <int ROWS, int NW>
-__device__ __forceinline__ void ring_stage(const char* __restrict__ base, const uint32_t (&off)[ROWS / 16 / NW], char* lds, int wave) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 16 / NW; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(lds + (i * NW + wave) * 16 * 64), 16, 0, 0);
-}
-
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_ring_kernel(const GemmParams p) {
-    static_assert(NSTAGE >= 3, "stage t+2 is issued while stage t is being read");
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 16 / NW, B_INSTR = BN / 16 / NW, LOADS = A_INSTR + B_INSTR;
-    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split over waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
-    int tm, tn;
-    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
-    const int nk = p.K >> 5;
-    const int S = nk + (p.A2 ? (p.K2 >> 5) : 0);
-    const bool perm_b = p.perm_b != 0;
-
-    uint32_t offA[A_INSTR], offB[B_INSTR], offA2[A_INSTR], offB2[B_INSTR];
-    ring_offsets<BM, NW>(p.lda, m0, p.M - 1, wave, lane, offA, false);
-    ring_offsets<BN, NW>(p.ldb, n0, p.N - 1, wave, lane, offB, perm_b);
-    ring_offsets<BM, NW>(p.A2 ? p.lda2 : p.lda, m0, p.M - 1, wave, lane, offA2, false);
-    ring_offsets<BN, NW>(p.A2 ? p.ldb2 : p.ldb, n0, p.N - 1, wave, lane, offB2, perm_b);
-    const char* a2base = (const char*)(p.A2 ? p.A2 + (size_t)g * p.K2 : p.A);
-    const char* b2base = (const char*)(p.A2 ? p.B2 : p.B);
-    auto issue = [&](int t) {
-        char* la = smem + (t % NSTAGE) * STAGE;
-        char* lb = la + A_BYTES;
-        // one code path for both phases (a branch here made the compiler keep the offset arrays in scratch memory and
-        // drain vmcnt at every step): uniform base pointers + per-lane offsets selected by value
-        const bool ph2 = t >= nk;
-        const char* ab = ph2 ? a2base + (size_t)(t - nk) * 64 : (const char*)p.A + (size_t)t * 64;
-        const char* bb = ph2 ? b2base + (size_t)(t - nk) * 64 : (const char*)p.B + (size_t)t * 64;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const uint32_t o = ph2 ? offA2[i] : offA[i];
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab + o), (lptr_t)(la + (i * NW + wave) * 16 * 64), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const uint32_t o = ph2 ? offB2[i] : offB[i];
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb + o), (lptr_t)(lb + (i * NW + wave) * 16 * 64), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[TN][TM];
-    init_acc<TM, TN>(p, acc, n0 + wn * (BN / WN), lane);
-    const int frow = lane & 15, fq = lane >> 4;
-    // per-lane LDS byte offsets of the fragment reads (the same in every stage)
-    int ra[TM], rb[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm * (BM / WM) + i * 16 + frow;
-        ra[i] = row * 64 + (swz32(row, fq) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn * (BN / WN) + j * 16 + frow;
-        rb[j] = A_BYTES + row * 64 + (swz32(row, fq) << 4);
-    }
-
-    issue(0);
-    if (S > 1) issue(1);
-    for (int t = 0; t < S; ++t) {
-        // vmcnt counts this wave's LDS-DMA loads in issue order: stage t has landed once at most LOADS (stage t+1) remain
-        if (t + 1 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // stage t landed for every wave; everyone is done reading stage t-1
-        asm volatile("" ::: "memory");
-        if (t + 2 < S) issue(t + 2);                        // -> buffer (t+2) % NSTAGE, last read in step t-1
-        const char* st = smem + (t % NSTAGE) * STAGE;
-        // all fragment reads of the step are issued up front (left alone the compiler reuses ONE weight-fragment register
-        // and emits read -> lgkmcnt(0) -> 4 MFMAs eight times per step); the empty asm statements pin each half's
-        // registers, so the first half's MFMAs start under a counted lgkmcnt while the second half is still landing
-        bf16x8 af[TM], wf[TN];
-        constexpr int H = TN / 2;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + ra[i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + rb[j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
-#pragma unroll
-        for (int j = 0; j < H; ++j) asm volatile("" : "+v"(wf[j]));
-#pragma unroll
-        for (int j = 0; j < H; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
-#pragma unroll
-        for (int j = H; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
-#pragma unroll
-        for (int j = H; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
-    }
-    if (p.dbg != 1) store_tile<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
-}
-
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_ring(GemmParams& p, hipStream_t s) {
-    constexpr int LDS = NSTAGE * (BM + BN) * 64;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_ring_kernel<BM, BN, WM, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    const int grid = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((mer_gemm_ring_kernel<BM, BN, WM, WN, NSTAGE>), dim3(grid), dim3(WM * WN * 64), LDS, s, p);
-    REID_CHECK_LAUNCH("reid_mer_gemm(ring)");
-    return REID_OK;
-}
-
 template <int BM, int BN, int WM, int WN>
 int launch(GemmParams& p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
@@ -449,10 +299,6 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     const char* e_dbg = getenv("REID_GEMM_DBG");
     const int tile = e_tile ? atoi(e_tile) : 0;
     p.dbg = e_dbg ? atoi(e_dbg) : 0;
-    if (tile == 9) return launch_ring<128, 256, 2, 2, 3>(p, s);
-    if (tile == 10) return launch_ring<128, 128, 2, 2, 3>(p, s);
-    if (tile == 11) return launch_ring<128, 256, 2, 4, 3>(p, s);
-    if (tile == 1) return launch<256, 128, 4, 2>(p, s);
     if (tile == 2) return launch<256, 256, 2, 4>(p, s);
     if (tile == 3) return launch<128, 128, 2, 2>(p, s);
     if (tile == 8) return launch<128, 256, 2, 4>(p, s);
@@ -461,5 +307,9 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     // as the 256x256 tile's (~1.0-1.1 PF on these shapes) and, unlike one big workgroup per CU, one workgroup's stores
     // overlap the other's MFMAs (sum over the seven shapes: 1.90 ms vs 2.04-2.17 ms for 256x256 / 128x256 tiles).
     // (k2_group_n is a multiple of 128, so a column tile never straddles two LoRA groups of the fused q|k|v projection.)
+    // Tried and dropped in r01 (same harness): LDS-ring variants with 32-wide K steps and counted vmcnt (128x256 tile with 4
+    // waves of 64x128, 128x128 with 2/3/4 stages at 2/3/4 workgroups per CU): 5-25 % slower than this on every shape;
+    // a DPP lane exchange that makes the epilogue store 128 contiguous bytes per row: slower (the DPP hazards cost more
+    // than the wider segments give).
     return launch<128, 128, 2, 2>(p, s);
 }

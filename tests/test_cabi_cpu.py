@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(ROOT, 'include', 'reid_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    names = re.findall(r'^\s*(?:const\s+char\s*\*|int64_t|int)\s+(reid_\w+)\s*\(', src, flags=re.M)
+    names = re.findall(r'^\s*(?:const\s+char\s*\*|int64_t|int32_t|int)\s+(reid_\w+)\s*\(', src, flags=re.M)
     return sorted(set(names))
 
 
