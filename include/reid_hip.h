@@ -286,6 +286,24 @@ int reid_opt_clip(const float* ws, int32_t n_entries, float* state, int32_t adap
 int reid_opt_adamw(const void* table, int32_t n_entries, const float* coef, float beta1, float beta2, float eps,
                    int32_t step, int32_t zero_grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AP / CMC from fp32 similarity rows: the metric half of rank_and_metrics,
+ * tools/eval_mm_protocol.py:401-469 (and _reid_map, train.py:450-479) without sorting the gallery.
+ *   scores  f32 [nq, ld] (ld % 4 == 0, 16-byte aligned): cosine similarities of nq queries against Ng gallery rows
+ *   g_pid   i32 [Ng]; g_img i32 [Ng] image ids (NULL or -1 = none)
+ *   q_pid   i32 [nq]; q_slot i32 [nq] = row of the query's pid in the CSR below, -1 if the pid has no gallery row
+ *   q_excl  i32 [nq, 4] image ids whose gallery rows are ignored for that query (-1 = unused; NULL = no masking)
+ *   csr_off i32 [n_pid + 1], csr_idx i32 [Ng]: gallery rows grouped by pid
+ * outputs per query: ap f64 (0 when there is no positive), rank1 i32 = rank of the best positive (CMC@k = rank1 <= k),
+ *   npos i32 = number of unmasked positives (0: the reference skips the query; -1: more than 8192, not evaluated).
+ *   max_pos = length of the longest CSR row (sizes the LDS list of positives).
+ * Ranking rule: score descending, gallery index ascending on ties (a stable descending argsort); masked rows rank last.
+ * ------------------------------------------------------------------------------------------ */
+int reid_rank_metrics(const float* scores, int64_t ld, const int32_t* g_pid, const int32_t* g_img,
+                      const int32_t* q_pid, const int32_t* q_slot, const int32_t* q_excl, const int32_t* csr_off,
+                      const int32_t* csr_idx, int32_t nq, int32_t Ng, int32_t max_pos, double* ap, int32_t* rank1,
+                      int32_t* npos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

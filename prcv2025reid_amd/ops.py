@@ -56,7 +56,7 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         a.img_mod = ptr(img_mod); a.mask_r = mask_r; a.mask_period = mask_period; a.rows_per_img = rows_per_img
     a.c_group, a.c_group_stride, a.c_row_off = c_group, c_group_stride, c_row_off
     a.alpha = alpha
-    if _gemm_profile is not None and a.N >= 256 and a.M >= 128 and a.k2_group_n % 256 == 0:   # both big-tile instantiations   # the 128x256-tile kernel (dominant); skinny LoRA projections use other tiles
+    if _gemm_profile is not None and a.N > 96:   # mer_gemm_kernel<128,128,2,2> (dominant); skinny LoRA projections use other tiles
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))
@@ -279,3 +279,10 @@ def small_attn_bwd(qkv, probs, dout, dqkv, n_seq, S, heads):
 def masked_mean(x, mask, out, B, M, D, backward=False):
     check(lib().reid_masked_mean(ptr(x), ptr(mask), ptr(out), B, M, D, int(backward), stream_ptr()))
     return out
+
+
+def rank_metrics(scores, g_pid, g_img, q_pid, q_slot, q_excl, csr_off, csr_idx, Ng, max_pos, ap, rank1, npos):
+    """Per-query AP / first-positive rank / #positives from fp32 score rows (reid_rank_metrics, include/reid_hip.h)."""
+    check(lib().reid_rank_metrics(ptr(scores), C.c_int64(scores.stride(0)), ptr(g_pid), ptr(g_img), ptr(q_pid), ptr(q_slot),
+                                  ptr(q_excl), ptr(csr_off), ptr(csr_idx), scores.shape[0], Ng, max_pos, ptr(ap), ptr(rank1), ptr(npos),
+                                  stream_ptr()))
