@@ -134,6 +134,9 @@ class FusedAdamW:
         coef = C.c_void_p(self.state.data_ptr() + 8)         # state[2]
         check(lib().reid_opt_adamw(ptr(self._table), n, coef, C.c_float(self.betas[0]), C.c_float(self.betas[1]),
                                    C.c_float(self.eps), self.step_count, int(zero_grad), stream_ptr()))
+        # the kernel wrote through raw pointers: tell autograd / the engine's pack cache (engine.refresh keys on _version)
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
 
     def stats(self) -> Dict[str, float]:
         """Host copy of the last step's statistics (synchronises)."""

@@ -49,6 +49,9 @@ from prcv2025reid_amd.weights import seeded_fill, fingerprint, param_spec  # noq
 from prcv2025reid_amd.synthetic import synthetic_batch                  # noqa: E402
 
 
+RANDOMIZE_HF = False
+
+
 def build_reference(cfg, num_classes, seed):
     from transformers import CLIPModel, CLIPConfig
     import models.clip_backbone as cb
@@ -67,7 +70,12 @@ def build_reference(cfg, num_classes, seed):
     class _LocalCLIP:
         @staticmethod
         def from_pretrained(name):
-            return CLIPModel(hf_cfg)
+            m = CLIPModel(hf_cfg)
+            if RANDOMIZE_HF:                     # distinct values everywhere: construction-time copies become identifiable
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.normal_()
+            return m
 
     class _LocalTok:
         @staticmethod
@@ -276,12 +284,65 @@ def make_retrieval_cases():
     print(f'[sdm] quick_check={v!r} second={v2!r}')
 
 
+# --------------------------------------------------------------------------- checkpoint layout
+def make_state_keys():
+    """state_keys.json: every key / shape / dtype of the reference model's state_dict() (tiny and full architecture) and, for
+    the keys the hot path never reads, which live tensor they are a construction-time copy of (found by comparing values in a
+    freshly built reference model, before the seeded overwrite) -- the pin of prcv2025reid_amd/checkpoint.py."""
+    import json
+    out = {}
+    for name, cfg, C in (('tiny', tiny_cfg(4), 5), ('full', full_cfg(8), 16)):
+        from transformers import CLIPModel  # noqa: F401  (build_reference rebinds the loader)
+        import models.clip_backbone as cb  # noqa: F401
+        # same construction as build_reference but WITHOUT the seeded overwrite: copies are still equal
+        torch.manual_seed(1234)
+        import importlib
+        m = build_reference.__wrapped__(cfg, C) if hasattr(build_reference, '__wrapped__') else _build_plain(cfg, C)
+        sd = m.state_dict()
+        keys = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in sd.items()]
+        from prcv2025reid_amd.weights import is_dead_key
+        live = {k: v for k, v in sd.items() if not is_dead_key(k)}
+        src = {}
+        for k, v in sd.items():
+            if not is_dead_key(k):
+                continue
+            hit = None
+            for lk, lv in live.items():
+                if lv.numel() == v.numel() and v.numel() > 1 and torch.equal(lv.reshape(-1).float(), v.reshape(-1).float()):
+                    hit = lk
+                    break
+            if hit is None:
+                vv = v.float().reshape(-1)
+                hit = 'const:%r' % float(vv[0]) if bool((vv == vv[0]).all()) else 'free'
+            src[k] = hit
+        out[name] = {'keys': keys, 'dead_source': src}
+        print(f'[state_keys/{name}] {len(keys)} keys, {len(src)} dead: '
+              f'{sum(1 for x in src.values() if not x.startswith(("const", "free")))} copies, '
+              f'{sum(1 for x in src.values() if x.startswith("const"))} constants, {sum(1 for x in src.values() if x == "free")} free')
+    json.dump(out, open(os.path.join(HERE, 'state_keys.json'), 'w'), indent=0)
+
+
+def _build_plain(cfg, num_classes):
+    """build_reference without seeded_fill (construction-time values as the reference produces them)."""
+    import prcv2025reid_amd.weights as W
+    orig = W.seeded_fill
+    try:
+        globals()['seeded_fill'] = lambda sd, seed: None
+        globals()['RANDOMIZE_HF'] = True
+        return build_reference(cfg, num_classes, 0)
+    finally:
+        globals()['seeded_fill'] = orig
+        globals()['RANDOMIZE_HF'] = False
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'retrieval'])
+    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'retrieval', 'statekeys'])
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.only in (None, 'retrieval'):
         make_retrieval_cases()
     if args.only in (None, 'tiny', 'full'):
         make_model_cases(args.only)
+    if args.only in (None, 'statekeys'):
+        make_state_keys()
