@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-retrieval', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'])
+    ap.add_argument('--graph', default='off', choices=['auto', 'on', 'off'],
+                    help='replay the step as a HIP graph (single process only; measured ~1 ms/step SLOWER than eager launches on MI355X, r01)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for rehearsals')
     ap.add_argument('--compute-dtype', default=None, choices=[None, 'bf16', 'f16'])
     return ap.parse_args()
@@ -186,13 +188,28 @@ def main():
     groups = [dict(params=[p for p in g['params'] if p.requires_grad], lr=g['lr'], name=g['name'])
               for g in model.get_learnable_params()]
     groups = [g for g in groups if g['params']]
+    graphed = False
     if args.optimizer == 'fused':
         # the reference's step (train.py:975-1047): sanitise, adaptive clip, AdamW -- three fused launches, no host sync
-        from prcv2025reid_amd.trainer import FusedAdamW, StepDriver
+        from prcv2025reid_amd.trainer import FusedAdamW, StepDriver, GraphedStep
         opt = FusedAdamW(groups, weight_decay=1e-4)
         driver = StepDriver(dp, opt, accum_steps=1, adaptive_clip=True, dp=dp)
+        gstep = None
+        if world == 1 and args.graph != 'off':
+            try:       # single process: the whole step replayed as one HIP graph (inputs copied into static buffers)
+                gstep = GraphedStep(driver, images, tokens, masks, labels, warmup=1)
+                graphed = True
+            except Exception as e:                       # same HIP kernels, launched eagerly
+                log(f'HIP graph capture failed ({type(e).__name__}: {e}); running the step eagerly')
+                if args.graph == 'on':
+                    raise
 
         def step():
+            if gstep is not None:
+                return gstep.step(images, tokens, masks, labels)
+            return driver.step(images, tokens, masks, labels)
+
+        def eager_step():
             return driver.step(images, tokens, masks, labels)
     else:
         opt = torch.optim.AdamW(groups, weight_decay=1e-4)
@@ -205,6 +222,7 @@ def main():
             dp.reduce_grads()
             opt.step()
             return L
+        eager_step = step
 
     log(f'model built, {args.warmup} warm-up steps')
     for _ in range(args.warmup):
@@ -229,7 +247,7 @@ def main():
         ops.gemm_profile_begin(); ops.ln_profile_begin()
         te = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            eager_step()                                 # (a replayed graph launches nothing from Python: the event pass is eager)
         torch.cuda.synchronize()
         ms_with_events = (time.perf_counter() - te) / args.steps * 1e3
         prof = ops.gemm_profile_end(); ln_prof = ops.ln_profile_end()
@@ -255,13 +273,13 @@ def main():
                        'P': P, 'K': K, 'global_batch': world * B, 'lora_rank': args.rank, 'parallelism': f'dp{world}'},
             'model_tflops_per_gpu': value / world * FLOP_PER_INSTANCE / 1e12,
             'mfma_frac_whole_step': value / world * FLOP_PER_INSTANCE / 1e12 / PEAK_BF16_TFLOPS,
-            'final_loss': loss,
+            'final_loss': loss, 'hip_graph': graphed,
         }
         if prof:
             fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
             ach = fl / (ms * 1e-3) / 1e12
-            res['roofline'] = {'kernel': 'mer_gemm_kernel<256,256,2,4> + <128,256,2,4>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<256, 256, 2, 4>', 'mer_gemm_kernel<128, 256, 2, 4>'),
+            res['roofline'] = {'kernel': 'mer_gemm_kernel<128,128,2,2>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<128, 128, 2, 2>'),
                                'traffic_note': 'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic.md); null if not collected',
                                'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
                                'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,

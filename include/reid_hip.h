@@ -270,6 +270,9 @@ int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_
  *                   (state[5] = count, state[6..15] = last ten), max_norm = min(3, max(0.5, 1.15 * percentile70(last ten)))
  *                   once more than ten norms were recorded, else 1.0; adaptive == 0: max_norm = fixed_max_norm
  *   reid_opt_adamw  p, exp_avg, exp_avg_sq updated with gradient g * (*coef) (coef may be NULL = 1); step counts from 1;
+ *                   step == 0: the step counter and bias corrections live in state[16..18] and advance on the device, and
+ *                   reid_opt_clip's record < 0 means "record when (device batch counter state[19]) % (-record) == 0" -- the
+ *                   forms a captured HIP graph replays;
  *                   zero_grad != 0 clears g in the same pass (optimizer.zero_grad at the next accumulation window)
  * ------------------------------------------------------------------------------------------ */
 typedef struct reid_opt_entry {
@@ -284,7 +287,7 @@ int reid_opt_sumsq(const void* table, int32_t n_entries, float* ws, void* stream
 int reid_opt_clip(const float* ws, int32_t n_entries, float* state, int32_t adaptive, float fixed_max_norm,
                   int32_t record, void* stream);
 int reid_opt_adamw(const void* table, int32_t n_entries, const float* coef, float beta1, float beta2, float eps,
-                   int32_t step, int32_t zero_grad, void* stream);
+                   int32_t step, int32_t zero_grad, float* state, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * AP / CMC from fp32 similarity rows: the metric half of rank_and_metrics,

@@ -31,6 +31,7 @@ struct GemmParams {
     int c_group, c_group_stride, c_row_off;
     float alpha;
     int tiles_m, tiles_n;
+    int group_m;  // row tiles per L2 group of the tile order (gemm_core.h tile_coords)
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue
 };
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     // XCD-aware, L2-aware tile order (gemm_core.h)
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
     int tm, tn;
-    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn);
+    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
     const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
@@ -287,6 +288,10 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     p.c_group = a->c_group; p.c_group_stride = a->c_group_stride; p.c_row_off = a->c_row_off;
     p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
     p.dbg = 0;
+    // L2 group height of the tile order: 16 row tiles when the weight panel set is wide and K short (q|k|v, fc1: the whole
+    // [N, K] weight no longer fits one XCD's L2 next to 8 activation tiles and was re-streamed per group; r01 sweep 4..64)
+    p.group_m = (p.K + p.K2 <= 1024 && p.N >= 1536) ? 16 : 8;
+    { const char* e_g = getenv("REID_GEMM_GROUPM"); if (e_g && atoi(e_g) > 0) p.group_m = atoi(e_g); }
     p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding

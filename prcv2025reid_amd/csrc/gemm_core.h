@@ -89,8 +89,7 @@ __device__ __forceinline__ int xcd_linear_block(int bid, int nwg) {
 // column-tiles before moving on, so the ~64 tiles an XCD has in flight reuse the same GROUP_M activation blocks and a
 // handful of weight panels (both stay in the 4 MiB L2); with the plain "m fastest" order every weight panel pass
 // re-streamed the whole activation matrix from the Infinity Cache (18 x 81 MB per QKV GEMM).
-__device__ __forceinline__ void tile_coords(int lin, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int lin, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = 8) {
     const int per_group = GROUP_M * tiles_n;
     const int gid = lin / per_group;
     const int first_m = gid * GROUP_M;

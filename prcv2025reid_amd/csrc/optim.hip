@@ -22,6 +22,7 @@ struct OptEntry {            // 48 bytes, mirrored by prcv2025reid_amd/trainer.p
 
 constexpr int OPT_BLOCKS = 128;     // workgroups per table entry (grid = OPT_BLOCKS x n_entries)
 constexpr int ST_SUMSQ = 0, ST_NORM = 1, ST_COEF = 2, ST_MAXNORM = 3, ST_BAD = 4, ST_HCOUNT = 5, ST_HIST = 6;   // + 10 floats
+constexpr int ST_STEP = 16, ST_BC1 = 17, ST_BC2S = 18, ST_BATCH = 19, ST_FLOATS = 20;   // device-side counters (graph replay)
 
 __device__ __forceinline__ bool finite_f(float x) { return (__builtin_bit_cast(uint32_t, x) & 0x7f800000u) != 0x7f800000u; }
 
@@ -69,6 +70,11 @@ __global__ void opt_clip_kernel(const float* __restrict__ partial, const float* 
     for (int i = 0; i < n_partial; ++i) { s += (double)partial[i]; bad += (double)bad_partial[i]; }
     const double norm = sqrt(s);
     float max_norm = fixed_max_norm;
+    if (record < 0) {                                        // decided on the device: batch_idx % (-record) == 0 (HIP-graph replay)
+        const int bi = (int)state[ST_BATCH];
+        state[ST_BATCH] = (float)(bi + 1);
+        record = (bi % (-record)) == 0;
+    }
     if (adaptive) {
         float cnt = state[ST_HCOUNT];
         if (record) {                                      // grad_norms.append(total_norm): ring of the last 10
@@ -100,7 +106,16 @@ __global__ void opt_clip_kernel(const float* __restrict__ partial, const float* 
     state[ST_SUMSQ] = (float)s; state[ST_NORM] = nf; state[ST_COEF] = coef; state[ST_MAXNORM] = max_norm; state[ST_BAD] = (float)bad;
 }
 
-struct AdamHp { float beta1, beta2, eps, step_bc1, bc2_sqrt; int zero_grad; };
+struct AdamHp { float beta1, beta2, eps, step_bc1, bc2_sqrt; int zero_grad; const float* dev_bc; };
+
+// step counter and bias corrections kept on the device (a captured HIP graph replays the same kernel arguments every step)
+__global__ void opt_tick_kernel(float* __restrict__ state, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t = (double)state[ST_STEP] + 1.0;
+    state[ST_STEP] = (float)t;
+    state[ST_BC1] = (float)(1.0 - pow((double)beta1, t));
+    state[ST_BC2S] = (float)sqrt(1.0 - pow((double)beta2, t));
+}
 
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float lr, float wd, const AdamHp& h) {
     p *= 1.f - lr * wd;                                     // decoupled weight decay
@@ -111,9 +126,10 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(256) void opt_adamw_kernel(const OptEntry* __restrict__ table, const float* __restrict__ coef_ptr,
-                                                        const AdamHp h) {
+                                                        AdamHp h) {
     const OptEntry e = table[blockIdx.y];
     if (!e.g) return;
+    if (h.dev_bc) { h.step_bc1 = h.dev_bc[0]; h.bc2_sqrt = h.dev_bc[1]; }
     const float coef = coef_ptr ? *coef_ptr : 1.f;
     const long long n4 = e.n >> 2;
     f32x4 *p4 = (f32x4*)e.p, *g4 = (f32x4*)e.g, *m4 = (f32x4*)e.m, *v4 = (f32x4*)e.v;
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void opt_adamw_kernel(const OptEntry* __restri
 
 extern "C" int32_t reid_opt_entry_bytes(void) { return (int32_t)sizeof(OptEntry); }
 extern "C" int32_t reid_opt_ws_floats(int32_t n_entries) { return 2 * OPT_BLOCKS * n_entries; }
-extern "C" int32_t reid_opt_state_floats(void) { return ST_HIST + 10; }
+extern "C" int32_t reid_opt_state_floats(void) { return ST_FLOATS; }
 
 extern "C" int reid_opt_sumsq(const void* table, int32_t n_entries, float* ws, void* stream) {
     REID_CHECK_ARG(table && ws && n_entries > 0, "reid_opt_sumsq: bad args");
@@ -163,14 +179,22 @@ extern "C" int reid_opt_clip(const float* ws, int32_t n_entries, float* state, i
 }
 
 extern "C" int reid_opt_adamw(const void* table, int32_t n_entries, const float* coef, float beta1, float beta2, float eps,
-                              int32_t step, int32_t zero_grad, void* stream) {
-    REID_CHECK_ARG(table && n_entries > 0 && step >= 1, "reid_opt_adamw: bad args (step counts from 1)");
+                              int32_t step, int32_t zero_grad, float* state, void* stream) {
+    REID_CHECK_ARG(table && n_entries > 0 && (step >= 1 || (step == 0 && state)), "reid_opt_adamw: bad args (step counts from 1; 0 = device counter in state)");
     REID_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, "reid_opt_adamw: betas/eps");
     AdamHp h;
     h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
-    h.step_bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    h.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     h.zero_grad = zero_grad;
+    h.dev_bc = nullptr;
+    if (step >= 1) {
+        h.step_bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+        h.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    } else {
+        h.step_bc1 = h.bc2_sqrt = 1.f;
+        hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+        REID_CHECK_LAUNCH("reid_opt_adamw(tick)");
+        h.dev_bc = state + ST_BC1;
+    }
     hipLaunchKernelGGL(opt_adamw_kernel, dim3(OPT_BLOCKS, n_entries), dim3(256), 0, (hipStream_t)stream, (const OptEntry*)table, coef, h);
     REID_CHECK_LAUNCH("reid_opt_adamw");
     return REID_OK;

@@ -123,8 +123,20 @@ class Engine:
         self._lora_pack = None
         self._table = None
         self._side = None
+        self._consts = {}
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.W = {}
+
+    def _const(self, key, make):
+        """Small index tensors that depend only on the batch layout: built once per layout and kept on the device (a
+        host->device copy per step would also make the step impossible to capture in a HIP graph)."""
+        t = self._consts.get(key)
+        if t is None:
+            if len(self._consts) > 64:
+                self._consts.clear()
+            t = make().to(self.dev)
+            self._consts[key] = t
+        return t
 
     def _side_stream(self):
         if self._side is None:
@@ -193,7 +205,7 @@ class Engine:
         mods = []
         for mu, img in groups:
             mods += [mu] * img.shape[0]
-        img_mod = torch.tensor(mods, dtype=torch.int32).to(dev, non_blocking=True)
+        img_mod = self._const(('img_mod', tuple(mods)), lambda: torch.tensor(mods, dtype=torch.int32))
         f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
         x = torch.empty(M, d, **f32)
         pos = P[ce + 'vision_pos_embed']
@@ -254,7 +266,7 @@ class Engine:
                 saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
                                   mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2))
             x = xn
-        idx = (torch.arange(n_img, dtype=torch.int32) * S).to(dev, non_blocking=True)
+        idx = self._const(('cls_idx', n_img, S), lambda: torch.arange(n_img, dtype=torch.int32) * S)
         cls_h = torch.empty(n_img, d, **b16); mf = torch.empty(n_img, **f32); rf = torch.empty(n_img, **f32)
         ops.layernorm_fwd(x, P[ce + 'vision_ln_final.weight'], P[ce + 'vision_ln_final.bias'], y_bf16=cls_h, mean=mf, rstd=rf,
                           row_index=idx)

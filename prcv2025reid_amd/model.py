@@ -106,6 +106,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self.register_parameter('p/' + LORA_PARAM_NAME.replace('.', '/'), self.lora_arena)
         self._ref[LORA_PARAM_NAME] = self.lora_arena
         self.engine = Engine(self.arch, self._ref, self.lora_arena, dev)
+        self._plans = {}
         self.tokenizer = load_tokenizer(getattr(config, 'clip_model_name', ''), self.arch['text_vocab'],
                                         self.arch['text_bos_id'], self.arch['text_eos_id'], self.arch['text_max_len'])
         # facades so callers written against the reference's attribute paths keep working
@@ -299,6 +300,36 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             sm = torch.ones(B, M, device=x.device)
         return MaskedMeanFn.apply(z, sm)
 
+    def _plan(self, images, modality_masks, B):
+        """{modality: (kind 'all' | 'some' | 'none', device row indices or None, device mask f32 [B])}."""
+        dev = torch.device(self.device)
+        names = [m for m in (images or {}) if m in self.vision_modalities] + ['text']
+        host = {}
+        for m in names:
+            t = None if modality_masks is None else modality_masks.get(m)
+            if t is None:
+                host[m] = None
+            else:
+                host[m] = (t.detach().to('cpu') if torch.is_tensor(t) else torch.as_tensor(t)).float().contiguous()
+        key = (B, tuple((m, None if h is None else h.numpy().tobytes()) for m, h in host.items()))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        plan = {}
+        for m, h in host.items():
+            if h is None:            # no mask given: text counts as present, an image modality without a mask is absent (model.py:367)
+                plan[m] = ('all', None, torch.ones(B, device=dev)) if m == 'text' else ('none', None, torch.zeros(B, device=dev))
+            elif float(h.sum()) <= 0 and m != 'text':
+                plan[m] = ('none', None, torch.zeros(B, device=dev))
+            elif bool(h.bool().all()):
+                plan[m] = ('all', None, h.to(dev))
+            else:
+                plan[m] = ('some', h.bool().nonzero().flatten().to(dev), h.to(dev))
+        if len(self._plans) > 32:
+            self._plans.clear()
+        self._plans[key] = plan
+        return plan
+
     # ------------------------------------------------------------------ forward
     def forward(self, images: Optional[Dict[str, torch.Tensor]] = None, texts=None,
                 modality_masks: Optional[Dict[str, torch.Tensor]] = None, return_features: bool = False,
@@ -320,11 +351,10 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         B = batch_size
-        # one host copy of all masks (no per-modality .sum() syncs as in model.py:367)
-        host_masks = {}
-        if modality_masks is not None:
-            for m, t in modality_masks.items():
-                host_masks[m] = t.detach().to('cpu').float() if torch.is_tensor(t) else torch.as_tensor(t).float()
+        # Routing plan: which rows of which modality go through the encoder is decided from ONE host copy of the masks (no
+        # per-modality .sum() syncs as in model.py:367) and cached per mask pattern, together with the device copies of the
+        # index / mask tensors -- a repeated pattern (all-on masks, or a replayed HIP graph) costs no host<->device traffic.
+        plan = self._plan(images, modality_masks, B)
         raw: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         fmask: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         groups, order = [], []
@@ -332,15 +362,13 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             for m, img in images.items():
                 if m not in self.vision_modalities:
                     continue
-                hm = host_masks.get(m)
-                if hm is not None and float(hm.sum()) > 0:
-                    idx = hm.bool()
-                    all_on = bool(idx.all())
-                    sel = img if all_on else img[idx.to(img.device)]
-                    groups.append((self.vision_modalities.index(m), sel.to(dev).float()))
-                    order.append((m, None if all_on else idx.nonzero().flatten().to(dev), hm.to(dev)))
+                kind, sel_idx, mask_dev = plan[m]
+                if kind == 'none':
+                    order.append((m, 'none', mask_dev))
                 else:
-                    order.append((m, 'none', torch.zeros(B, device=dev)))
+                    sel = img.to(dev) if kind == 'all' else img.to(dev)[sel_idx]
+                    groups.append((self.vision_modalities.index(m), sel.float()))
+                    order.append((m, None if kind == 'all' else sel_idx, mask_dev))
         feats = None
         if groups:
             feats = VisionEncodeFn.apply(self.engine, tuple(g[0] for g in groups), self.lora_arena, *[g[1] for g in groups])
@@ -359,12 +387,9 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         if texts is not None and n_text > 0:
             ids, am = self._tokens(texts)
             tf = self.engine.text_forward(ids, am)
-            tm = host_masks.get('text')
-            if tm is not None:
-                tmd = tm.to(dev)
+            tmd = plan['text'][2]
+            if plan['text'][0] != 'all':
                 tf = torch.where(tmd.bool().view(B, 1), tf, self._ref['null_tokens.text'].expand(B, -1))
-            else:
-                tmd = torch.ones(B, device=dev)
             raw['text'] = tf; fmask['text'] = tmd
         if not raw:
             raise ValueError('at least one modality is required')

@@ -108,3 +108,43 @@ def test_step_driver_tiny_model():
         assert delta_a <= 0.05 * step_sz + 1e-7, (k, delta_a, step_sz)
         moved += step_sz > 1e-9
     assert moved >= 3
+
+
+def test_graphed_step_matches_eager():
+    """HIP-graph replay of the step == the eager StepDriver on a twin model (same kernels, same order)."""
+    from prcv2025reid_amd.trainer import FusedAdamW, StepDriver, GraphedStep
+    from test_model_gpu import build_model
+    z, meta = load_case('tiny_train_frozen')
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    images = {m: t.cuda() for m, t in batch['images'].items()}
+    masks = dict(batch['modality_mask'])
+    labels = batch['person_id'].cuda()
+
+    def make():
+        m = build_model(meta, state, True)
+        gs = [dict(params=[p for p in g['params'] if p.requires_grad], lr=g['lr'], name=g['name']) for g in m.get_learnable_params()]
+        return m, StepDriver(m, FusedAdamW(gs, weight_decay=1e-4))
+
+    a, da = make()
+    tok = a.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
+    tok = {k: v.cuda() for k, v in tok.items()}
+    init = {k: p.detach().clone() for k, p in a.named_parameters() if p.requires_grad}
+    g = GraphedStep(da, images, tok, masks, labels, warmup=2)          # 2 eager steps + the capture pass (not executed)
+    for _ in range(3):
+        La = g.step(images, tok, masks, labels)
+    torch.cuda.synchronize()
+    b, db = make()
+    for _ in range(5):
+        Lb = db.step(images, tok, masks, labels)
+    assert da.opt.step_count == db.opt.step_count == 5
+    sa, sb = da.opt.stats(), db.opt.stats()
+    assert abs(sa['grad_norm'] - sb['grad_norm']) <= 2e-2 * sb['grad_norm'], (sa, sb)
+    assert abs(float(La['total_loss']) - float(Lb['total_loss'])) <= 2e-3 * max(1.0, abs(float(Lb['total_loss'])))
+    pb = dict(b.named_parameters())
+    for k, p in a.named_parameters():
+        if p.requires_grad:
+            step_sz = float((pb[k].detach() - init[k]).float().norm())
+            assert float((p.detach() - pb[k].detach()).float().norm()) <= 0.05 * step_sz + 1e-7, k
+    with pytest.raises(ValueError):
+        bad = dict(masks); bad['nir'] = torch.zeros_like(masks['nir'])
+        g.step(images, tok, bad, labels)
