@@ -14,6 +14,7 @@
 // A query whose list overflowed is flagged (out_idx[q][0] = -2) and handled by the caller's exact
 // fallback (brute-force kernel below), so the result never silently degrades.
 #include "gemm_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -118,13 +119,60 @@ __global__ __launch_bounds__(256) void kth_kernel(const float* __restrict__ dens
     if (lane == 0) thr[q] = (rounds < k ? -INFINITY : kth - 2.f * EPS_BF16);
 }
 
+// Fast form of the same threshold for small k: every lane streams its share of the row with 16-byte loads and keeps its T
+// largest values in registers; the wave then pops the k largest of those 64 T values.  The popped values are k distinct sample
+// elements, so their smallest is a LOWER bound of the sample's k-th largest (equal unless more than T of the top k fell on one
+// lane): still a valid filter threshold, at most a few % more candidates, and no LDS / no k passes over the row
+// (the kernel above took 1.84 ms of the 7.1 ms retrieval at 10k x 8192; this one is HBM-bound).
+template <int T>
+__global__ __launch_bounds__(256) void kth_fast_kernel(const float* __restrict__ dense, int ld, int n, int k, float* __restrict__ thr, int Nq) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= Nq) return;
+    float top[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) top[t] = -INFINITY;
+    auto insert = [&](float v) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float hi = fmaxf(top[t], v);
+            v = fminf(top[t], v);
+            top[t] = hi;
+        }
+    };
+    const float* row = dense + (size_t)q * ld;
+    int done = 0;
+    if (((ld | n) & 3) == 0) {
+        for (int i = lane * 4; i < n; i += 256) {
+            const f32x4 v = *(const f32x4*)(row + i);
+            insert(v[0]); insert(v[1]); insert(v[2]); insert(v[3]);
+        }
+        done = n;
+    }
+    for (int i = done + lane; i < n; i += 64) insert(row[i]);
+    float kth = -INFINITY;
+    for (int r = 0; r < k; ++r) {
+        const float m = wave_max(top[0]);
+        kth = m;
+        const unsigned long long b = __ballot(top[0] == m);
+        const int win = __builtin_ctzll(b);
+        if (lane == win) {
+#pragma unroll
+            for (int t = 0; t + 1 < T; ++t) top[t] = top[t + 1];
+            top[T - 1] = -INFINITY;
+        }
+    }
+    if (lane == 0) thr[q] = (n < k ? -INFINITY : kth - 2.f * EPS_BF16);
+}
+
 // phase C: exact fp32 re-score of the candidates + top-k by (score desc, index asc)
 __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int D,
                                                      const int32_t* __restrict__ exq, const int32_t* __restrict__ exg,
-                                                     const int32_t* __restrict__ cand_idx, const int32_t* __restrict__ cand_cnt,
-                                                     int cap, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                     int Nq) {
+                                                     const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_score,
+                                                     const int32_t* __restrict__ cand_cnt, int cap, int k,
+                                                     int32_t* __restrict__ out_idx, float* __restrict__ out_score, int Nq) {
     extern __shared__ char sm2[];
+    __shared__ float thr2;
     volatile float* sc = (volatile float*)sm2;                  // [cap]
     volatile int32_t* ix = (volatile int32_t*)(sc + cap);       // [cap]
     float* qrow = (float*)((float*)sm2 + 2 * cap);         // [D]
@@ -136,10 +184,41 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Q
         return;
     }
     for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
+    // Second-level filter on the 16-bit-operand scores the filter pass saved: with a = k-th largest of them, a candidate below
+    // a - 2 eps cannot be in the exact top k (its true score is < a - eps <= the true score of each of the k candidates at or
+    // above a).  Only the survivors (about k + a few) pay the 2 KB fp32 gallery-row gather of the exact re-score; before,
+    // all ~250 candidates per query did (5 GB of gathers at 10k x 200k).
+    const float* cs = cand_score + (size_t)q * cap;
+    for (int c = tid; c < cnt; c += 256) sc[c] = cs[c];
     __syncthreads();
+    if (w == 0) {
+        float kth = -INFINITY;
+        const int rounds = k < cnt ? k : cnt;
+        for (int r = 0; r < rounds; ++r) {
+            float best = -INFINITY; int bpos = -1;
+            for (int c = lane; c < cnt; c += 64) {
+                const float v = sc[c];
+                if (v > best || bpos < 0) { best = v; bpos = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64); const int op = __shfl_xor(bpos, o, 64);
+                if (op >= 0 && (bpos < 0 || ob > best)) { best = ob; bpos = op; }
+            }
+            kth = best;
+            if (bpos >= 0 && (bpos & 63) == lane) sc[bpos] = -INFINITY;
+        }
+        if (lane == 0) thr2 = cnt < k ? -INFINITY : kth - 2.f * EPS_BF16;
+    }
+    __syncthreads();
+    const float t2 = thr2;
     const int eq = exq ? exq[q] : -1;
     for (int c = w; c < cnt; c += 4) {
         const int gi = cand_idx[(size_t)q * cap + c];
+        if (cs[c] < t2) {                                      // wave-uniform
+            if (lane == 0) { sc[c] = -INFINITY; ix[c] = -1; }
+            continue;
+        }
         const float* g = Gf + (size_t)gi * D;
         float s = 0.f;
         for (int i = lane * 4; i < D; i += 256) {
@@ -248,6 +327,23 @@ extern "C" int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k) {
     return (int64_t)Nq * 8 + (int64_t)Nq * cap * 8 + (int64_t)Nq * ns * 4 + 256;
 }
 
+namespace {
+template <int BM, int BN, int WM, int WN>
+int launch_filter(TopkParams p, hipStream_t s) {
+    using C = Cfg<BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    p.tiles_m = (p.Nq + BM - 1) / BM;
+    p.tiles_n = (p.Ng + BN - 1) / BN;
+    hipLaunchKernelGGL((score_kernel<BM, BN, WM, WN, false>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    REID_CHECK_LAUNCH("reid_cosine_topk(filter)");
+    return REID_OK;
+}
+}  // namespace
+
 extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf, int32_t Nq, int32_t Ng,
                                 int32_t D, int32_t k, const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
                                 float* out_score, void* stream) {
@@ -279,20 +375,31 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     REID_CHECK_LAUNCH("reid_cosine_topk(sample)");
     static bool attr2 = false;
     if (!attr2) { (void)hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SAMPLE * 4); attr2 = true; }   // 128 KiB: 4 waves x 8192 floats
-    hipLaunchKernelGGL(kth_kernel, dim3((Nq + 3) / 4), dim3(256), 4 * ns * sizeof(float), s, dense, ns, ns, k, thr, Nq);
+    if (k <= 32) hipLaunchKernelGGL(kth_fast_kernel<2>, dim3((Nq + 3) / 4), dim3(256), 0, s, dense, ns, ns, k, thr, Nq);
+    else if (k <= 128) hipLaunchKernelGGL(kth_fast_kernel<4>, dim3((Nq + 3) / 4), dim3(256), 0, s, dense, ns, ns, k, thr, Nq);
+    else hipLaunchKernelGGL(kth_kernel, dim3((Nq + 3) / 4), dim3(256), 4 * ns * sizeof(float), s, dense, ns, ns, k, thr, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(kth)");
     // phase B: filter the whole gallery
     (void)hipMemsetAsync(cnt, 0, (size_t)Nq * sizeof(int32_t), s);
     p.g_begin = 0; p.g_end = Ng; p.thr = thr; p.dense = nullptr;
     p.cand_idx = cidx; p.cand_score = cscore; p.cand_cnt = cnt;
-    p.tiles_n = (Ng + BN - 1) / BN;
-    hipLaunchKernelGGL((score_kernel<BM, BN, 2, 2, false>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
-    REID_CHECK_LAUNCH("reid_cosine_topk(filter)");
+    {
+        const char* e = getenv("REID_TOPK_TILE");
+        // the filter epilogue is a compare (stores are rare), so unlike the training GEMMs the 256x256 tile wins here:
+        // 10k x 200k x 512: 3.35 ms vs 3.68 ms with 128x128 (REID_TOPK_TILE=0/1/2/3 A/B, r01)
+        const int tile = e ? atoi(e) : ((Nq >= 512 && Ng >= 4096) ? 3 : 0);
+        int rc;
+        if (tile == 1) rc = launch_filter<256, 128, 4, 2>(p, s);
+        else if (tile == 2) rc = launch_filter<128, 256, 2, 4>(p, s);
+        else if (tile == 3) rc = launch_filter<256, 256, 2, 4>(p, s);
+        else rc = launch_filter<128, 128, 2, 2>(p, s);
+        if (rc) return rc;
+    }
     // phase C
     const size_t lds = (size_t)cap * 8 + (size_t)D * 4;
     static bool attr3 = false;
     if (!attr3) { (void)hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 1024 * 4); attr3 = true; }
-    hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cnt, cap, k, out_idx, out_score, Nq);
+    hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt, cap, k, out_idx, out_score, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(select)");
     return REID_OK;
 }
