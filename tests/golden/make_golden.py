@@ -284,6 +284,93 @@ def make_retrieval_cases():
     print(f'[sdm] quick_check={v!r} second={v2!r}')
 
 
+# --------------------------------------------------------------------------- input pipeline
+def _pipeline_samples(seed, n_pid=9, image_size=224):
+    """Synthetic sample dictionaries in the reference dataset's format, with every irregularity the collate handles."""
+    import random as pyrandom
+    g = torch.Generator().manual_seed(seed)
+    R = pyrandom.Random(seed)
+    samples = []
+    for pid in range(1, n_pid + 1):
+        for j in range(R.randint(2, 7)):
+            kind = R.choice(['vis', 'vis', 'nir', 'sk', 'cp', 'multi'])
+            imgs, mask = {}, {}
+            mods = ['vis', 'nir', 'sk', 'cp'] if kind == 'multi' else [kind]
+            if pid == 3:
+                mods = ['vis']                      # a soft identity: vis only, no caption
+            for m in ['vis', 'nir', 'sk', 'cp']:
+                if m in mods:
+                    imgs[m] = torch.randn(3, image_size, image_size, generator=g)
+                    mask[m] = 1.0
+                elif R.random() < 0.3:
+                    imgs[m] = torch.zeros(3, image_size, image_size)      # zero placeholder that claims to be present
+                    mask[m] = 1.0
+                else:
+                    mask[m] = 0.0
+            if R.random() < 0.15 and 'nir' in imgs:
+                mask['nir'] = False
+            cap = '' if pid == 3 else R.choice(['a person walking', '  ', 'red coat, black bag', ''])
+            s = {'person_id': torch.tensor(pid), 'images': imgs, 'modality_mask': mask,
+                 'text_description': [cap] if R.random() < 0.8 else cap}
+            if R.random() < 0.5:
+                s['modality'] = R.choice(['RGB', 'ir', 'sketch', 'cpencil', 'vis'])
+            samples.append(s)
+    return samples
+
+
+def make_pipeline_cases():
+    """pipeline_cases.json: the reference's own sampler and collate (datasets/dataset.py, pulled out by ``ast`` because the
+    module imports torchvision) run on seeded synthetic samples: index lists of the strict P x K sampler under a seeded
+    ``random``, and the collate's masks / primary modalities / image checksums."""
+    import json
+    import random as pyrandom
+    path = os.path.join(REF, 'datasets', 'dataset.py')
+    src = open(path, encoding='utf-8').read()
+    tree = ast.parse(src)
+    want_f = {'canon_mod', '_truthy', 'infer_modalities_of_sample', 'compatible_collate_fn'}
+    want_a = {'CANON_DS', 'IMG_MODALITIES', 'ALL_MODALITIES'}
+    chunks = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want_f:
+            chunks.append(ast.get_source_segment(src, node))
+        elif isinstance(node, ast.ClassDef) and node.name == 'ModalAwarePKBatchSampler_Strict':
+            chunks.append(ast.get_source_segment(src, node))
+        elif isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id in want_a for t in node.targets):
+            chunks.append(ast.get_source_segment(src, node))
+    from torch.utils.data import Sampler
+    ns = {'torch': torch, 'random': pyrandom, 'Sampler': Sampler}
+    exec('\n\n'.join(chunks), ns)
+
+    class DS:
+        def __init__(self, samples):
+            self.samples = samples
+        def __len__(self):
+            return len(self.samples)
+        def __getitem__(self, i):
+            return self.samples[i]
+
+    out = {'sampler': [], 'collate': []}
+    for seed, P, K, reuse in ((0, 3, 4, True), (1, 4, 3, True), (2, 2, 4, False), (3, 5, 2, True)):
+        samples = _pipeline_samples(seed)
+        sm = ns['ModalAwarePKBatchSampler_Strict'](DS(samples), num_ids_per_batch=P, num_instances=K, allow_id_reuse=reuse)
+        pyrandom.seed(100 + seed)
+        batches = []
+        for b in sm:
+            batches.append(list(map(int, b)))
+            if len(batches) >= min(6, len(sm)):       # (without id reuse the reference loops forever once its pools run low)
+                break
+        out['sampler'].append({'seed': seed, 'P': P, 'K': K, 'reuse': reuse, 'rng_seed': 100 + seed, 'len': len(sm),
+                               'strong_ids': list(map(int, sm.strong_ids)), 'soft_ids': list(map(int, sm.soft_ids)), 'batches': batches})
+        cb = ns['compatible_collate_fn']([samples[i] for i in batches[0]])
+        out['collate'].append({'seed': seed, 'indices': batches[0], 'person_id': cb['person_id'].tolist(),
+                               'text_description': cb['text_description'], 'modality': cb['modality'],
+                               'modality_mask': {m: v.tolist() for m, v in cb['modality_mask'].items()},
+                               'image_sums': {m: [float(x) for x in v.double().flatten(1).sum(1)] for m, v in cb['images'].items()},
+                               'image_shapes': {m: list(v.shape) for m, v in cb['images'].items()}})
+    json.dump(out, open(os.path.join(HERE, 'pipeline_cases.json'), 'w'))
+    print(f"[pipeline] {sum(len(c['batches']) for c in out['sampler'])} sampler batches, {len(out['collate'])} collate cases")
+
+
 # --------------------------------------------------------------------------- checkpoint layout
 def make_state_keys():
     """state_keys.json: every key / shape / dtype of the reference model's state_dict() (tiny and full architecture) and, for
@@ -337,7 +424,7 @@ def _build_plain(cfg, num_classes):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'retrieval', 'statekeys'])
+    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'retrieval', 'statekeys', 'pipeline'])
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.only in (None, 'retrieval'):
@@ -346,3 +433,5 @@ if __name__ == '__main__':
         make_model_cases(args.only)
     if args.only in (None, 'statekeys'):
         make_state_keys()
+    if args.only in (None, 'pipeline'):
+        make_pipeline_cases()
