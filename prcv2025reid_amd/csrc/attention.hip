@@ -11,6 +11,7 @@
 // lane, dQ with queries on the lane), each needing only products that sum over the accumulator's
 // row index; P is recomputed from the saved log-sum-exp.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -115,11 +116,17 @@ struct AttnParams {
     bf16_t* out; int ldo; float* lse;
     const bf16_t* dout; bf16_t* dqkv; int lddqkv; float* delta;
     int n_seq, S, heads, causal;
+    int dbg;     // timing experiments (REID_ATTN_DBG): 1 = no output stores, 2 = also no softmax / P.V, 3 = staging only
 };
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NT>   // number of 32-row tiles: S <= 32*NT
-__global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
+// TWO_PASS (long sequences): the score tiles are NOT kept in registers.  Pass 1 computes them for the row maximum only,
+// pass 2 recomputes each tile, exponentiates it and feeds it straight into the P.V MFMAs.  The 28 extra MFMAs per wave
+// are cheap next to what they buy: ~100 instead of ~200 VGPRs, so TWO workgroups fit a CU (LDS 56 KiB each) and one's
+// K/V staging and output stores overlap the other's MFMAs and softmax (a single resident workgroup ran load -> compute ->
+// store strictly in sequence).  Short sequences (text tower, NT <= 3) keep the single pass.
+template <int NT, bool TWO_PASS>   // number of 32-row tiles: S <= 32*NT
+__global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + NT * 32 * 128;
@@ -140,69 +147,99 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd_kernel(const AttnParams p) {
     __syncthreads();
     if (q0 >= p.S) return;   // wave-uniform; no barrier follows
 
+    if (p.dbg == 3) return;
     const FragOff fo = make_frag_off(lane);
-    f32x16 st[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[kt] = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], st[kt]);
-    }
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     const int h4 = 4 * (lane >> 5);
-    if (km || p.causal) {            // general masks (text tower, fusion): per-element predicate
+    const bool general = km != nullptr || p.causal;    // general masks (text tower, fusion): per-element predicate
+    // masked score tile kt: S^T = K.Q^T, rows = keys (registers), columns = queries (lanes)
+    auto score_tile = [&](int kt) -> f32x16 {
+        f32x16 t;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int e = 0; e < 16; ++e) t[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) t = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], t);
+        if (general) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
                 bool ok = key < p.S;
                 if (ok && km) ok = km[key] != 0;
                 if (p.causal) ok = ok && key <= qi;
-                st[kt][e] = ok ? st[kt][e] : -INFINITY;
+                t[e] = ok ? t[e] : -INFINITY;
             }
-    } else {                         // vision: only the padded keys of the last tile are masked
-        constexpr int kt = NT - 1;
+        } else if (kt == NT - 1) {                      // vision: only the padded keys of the last tile are masked
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
-            st[kt][e] = key < p.S ? st[kt][e] : -INFINITY;
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+                t[e] = key < p.S ? t[e] : -INFINITY;
+            }
         }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(st[kt][e], st[kt][e + 1]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (mx == -INFINITY) mx = 0.f;
+        return t;
+    };
     const float c = 0.125f * LOG2E;     // head_dim^-0.5 (mer_lora.py:128-129), exp via exp2
-    const float nmc = -mx * c;
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pe = fast_exp2(fmaf(st[kt][e], c, nmc));
-            st[kt][e] = pe;
-            l += pe;
-        }
-    l += __shfl_xor(l, 32, 64);
-
     f32x16 ot[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+    float mx = -INFINITY, l = 0.f;
+    if (TWO_PASS) {
+#pragma unroll 1
+        for (int kt = 0; kt < NT; ++kt) {               // (not unrolled: one tile's temporaries at a time keeps the kernel at <= 128 VGPRs)
+            const f32x16 t = score_tile(kt);
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack8(st[kt], s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(col_frag_o(Vs, kt * 32 + 16 * s2, dt, fo), pf, ot[dt]);
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(t[e], t[e + 1]));
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        const float nmc = -mx * c;
+#pragma unroll 1
+        for (int kt = 0; kt < (p.dbg == 2 ? 0 : NT); ++kt) {
+            f32x16 t = score_tile(kt);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = fast_exp2(fmaf(t[e], c, nmc));
+                t[e] = pe;
+                l += pe;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(t, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(col_frag_o(Vs, kt * 32 + 16 * s2, dt, fo), pf, ot[dt]);
+            }
+        }
+    } else {
+        f32x16 st[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) st[kt] = score_tile(kt);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(st[kt][e], st[kt][e + 1]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        const float nmc = -mx * c;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = fast_exp2(fmaf(st[kt][e], c, nmc));
+                st[kt][e] = pe;
+                l += pe;
+            }
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(st[kt], s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(col_frag_o(Vs, kt * 32 + 16 * s2, dt, fo), pf, ot[dt]);
+            }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (p.dbg >= 1 && l != 12345.678f) return;
     if (qi < p.S) {
         const float inv = 1.0f / l;
         bf16_t* orow = p.out + ((size_t)seq * p.S + qi) * p.ldo + head * 64;
@@ -428,8 +465,9 @@ template <int NT>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * NT * 32 * 128;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS, s, p);
+    constexpr bool TP = NT >= 4;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<NT, TP>), dim3(p.n_seq * p.heads), dim3(NT * 64), LDS, s, p);
     REID_CHECK_LAUNCH("reid_attn_fwd");
     return REID_OK;
 }
@@ -479,7 +517,8 @@ extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     int rc = check_common("reid_attn_fwd", qkv, ld, n_seq, S, heads);
     if (rc) return rc;
     REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
-    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal};
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, 0};
+    { const char* e = getenv("REID_ATTN_DBG"); if (e) p.dbg = atoi(e); }
     DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
 }
 
@@ -491,6 +530,6 @@ extern "C" int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     REID_CHECK_ARG(out && dout && lse && dqkv && delta_ws, "reid_attn_bwd: null pointer");
     REID_CHECK_ARG(ldo >= heads * 64 && ldo % 8 == 0 && lddqkv >= 3 * heads * 64 && lddqkv % 4 == 0, "reid_attn_bwd: ldo/lddqkv");
     AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, (float*)lse, (const bf16_t*)dout, (bf16_t*)dqkv, lddqkv,
-                 delta_ws, n_seq, S, heads, causal};
+                 delta_ws, n_seq, S, heads, causal, 0};
     DISPATCH_NT((S + 31) / 32, launch_bwd, p, (hipStream_t)stream)
 }

@@ -158,6 +158,9 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
         }
     };
 
+    // (r01 experiment: software-pipelining the fragment reads through two register sets -- reads of half-step h+1 issued before
+    //  the MFMAs of half-step h, buffer released as soon as its second half sits in registers -- changed nothing end to end
+    //  (sum of the seven ViT shapes 1.90 ms either way) and cost the 256x256 tile a register spill; not kept.)
     issue(0, 0);
     __syncthreads();   // vmcnt(0) + barrier: tile 0 landed for every wave
     int cur = 0;
