@@ -87,6 +87,8 @@ typedef struct {
     int32_t mask_r, mask_period, rows_per_img;
     int32_t c_group, c_group_stride, c_row_off;
     float alpha;
+    const float* row_scale;   /* optional f32 [rows / rows_per_img]: out = R + row_scale[row / rows_per_img] * (A.B^T + bias)  (DropPath,
+                                 clip_backbone.py:137-141: per-sample branch scale 0 or 1/keep); NULL = 1 */
 } reid_gemm_args;
 int reid_mer_gemm(const reid_gemm_args* host_args, void* stream);
 
@@ -108,6 +110,8 @@ int reid_gemm_tn(const void* X, const void* Y, float* C, int32_t M, int32_t P, i
  *   bwd: dx = dres + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;  dy bf16 or f32.
  *        writes dx f32 and optional bf16 copy; dgamma/dbeta (f32 [cols], atomically
  *        accumulated) only when non-NULL.  row_index != NULL scatters into rows of dx.
+ *        bf16_row_scale != NULL: the 16-bit copy is dx * bf16_row_scale[row / rows_per_img] (the gradient entering a
+ *        DropPath-scaled residual branch); the f32 dx is unscaled.
  * ------------------------------------------------------------------------------------------ */
 int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                        const float* beta, void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd,
@@ -115,7 +119,8 @@ int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, co
 int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
                        const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dx_bf16, int32_t lddx,
-                       float* dgamma, float* dbeta, int32_t rows, int32_t cols, void* stream);
+                       float* dgamma, float* dbeta, int32_t rows, int32_t cols,
+                       const float* bf16_row_scale, int32_t rows_per_img, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch extraction (im2col of the k=s=16 conv, models/patch_embeds.py:45-76):
@@ -243,15 +248,17 @@ int reid_sgemm(const float* A, const float* B, float* C, int32_t M, int32_t N, i
  *   reid_eltwise_f32: op 0 out=x+alpha*y, 1 relu(x), 2 relu' (x pre-activation, y = dy), 3 erf-GELU(x),
  *                     4 y*GELU'(x), 5 x*y, 6 nan_to_num(x, 0, 1e4, -1e4) (model.py:165)
  *   reid_small_attn_fwd/bwd: softmax(q k^T / 8 + key-padding mask) v over S <= 8 tokens, head_dim 64, fp32
- *                     (nn.MultiheadAttention, model.py:152-155); qkv [n_seq*S, ld] = q|k|v; probs [n_seq, heads, 8, 8] saved
+ *                     (nn.MultiheadAttention, model.py:152-155); qkv [n_seq*S, ld] = q|k|v; probs [n_seq, heads, 8, 8] saved;
+ *                     drop (optional, same layout as probs): attention-dropout multipliers 0 or 1/keep applied to the
+ *                     probabilities after the softmax (nn.MultiheadAttention(dropout=0.1), model.py:35,95)
  *   reid_masked_mean: out[b,:] = sum_m mask[b,m] x[b,m,:] / max(sum_m mask[b,m], 1) (model.py:168-178); backward != 0:
  *                     x = dout [B,D], out = dx [B,M,D]
  * ------------------------------------------------------------------------------------------ */
 int reid_eltwise_f32(int32_t op, const float* x, const float* y, float* out, int64_t n, float alpha, void* stream);
-int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, float* out, int32_t ldo, float* probs,
-                        int32_t n_seq, int32_t S, int32_t heads, void* stream);
-int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* dout, int32_t ldo, float* dqkv,
-                        int32_t lddqkv, int32_t n_seq, int32_t S, int32_t heads, void* stream);
+int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, const float* drop, float* out, int32_t ldo,
+                        float* probs, int32_t n_seq, int32_t S, int32_t heads, void* stream);
+int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* drop, const float* dout, int32_t ldo,
+                        float* dqkv, int32_t lddqkv, int32_t n_seq, int32_t S, int32_t heads, void* stream);
 int reid_masked_mean(const float* x, const float* mask, float* out, int32_t B, int32_t M, int32_t D, int32_t backward,
                      void* stream);
 /* L2-normalise rows (F.normalize, train.py:442): x f32 [rows, D] -> y f32 and/or bf16. */

@@ -112,23 +112,29 @@ def patch_embed(images, state, modality, patch):
 
 
 # --------------------------------------------------------------------------- A2-A6 vision encoder
-def vision_block(x, state, prefix, modality, heads, scaling):
+def vision_block(x, state, prefix, modality, heads, scaling, drop_scales=None):
     """MERTransformerBlock.forward, clip_backbone.py:61-85 (pre-LN, two residuals);
     attention = MERMultiheadAttention.forward mer_lora.py:141-231; MLP = MERMLP.forward
-    mer_lora.py:267-280 (erf GELU)."""
+    mer_lora.py:267-280 (erf GELU).  ``drop_scales`` = (s_attn [B], s_mlp [B]): the per-sample DropPath factors
+    ``floor(keep + U) / keep`` of clip_backbone.py:137-141, given explicitly so a test can fix the random draw."""
     h = layer_norm(x, state[prefix + '.ln1.weight'], state[prefix + '.ln1.bias'])
     q = mer_linear(h, state, prefix + '.attn.q_proj', modality, scaling)
     k = mer_linear(h, state, prefix + '.attn.k_proj', modality, scaling)
     v = mer_linear(h, state, prefix + '.attn.v_proj', modality, scaling)
     a = attention_core(q, k, v, heads)
-    x = x + mer_linear(a, state, prefix + '.attn.out_proj', modality, scaling)
+    br = mer_linear(a, state, prefix + '.attn.out_proj', modality, scaling)
+    if drop_scales is not None and drop_scales[0] is not None:
+        br = br * drop_scales[0].view(-1, 1, 1)
+    x = x + br
     h2 = layer_norm(x, state[prefix + '.ln2.weight'], state[prefix + '.ln2.bias'])
     u = mer_linear(h2, state, prefix + '.mlp.fc1', modality, scaling)
-    x = x + mer_linear(gelu_erf(u), state, prefix + '.mlp.fc2', modality, scaling)
-    return x
+    br = mer_linear(gelu_erf(u), state, prefix + '.mlp.fc2', modality, scaling)
+    if drop_scales is not None and drop_scales[1] is not None:
+        br = br * drop_scales[1].view(-1, 1, 1)
+    return x + br
 
 
-def encode_vision(images, modality, state, arch):
+def encode_vision(images, modality, state, arch, drop_scales=None):
     """CLIPUnifiedEncoder.encode_vision, clip_backbone.py:254-286.
 
     CLS + patches, + pos-embed, L blocks, final LN, CLS row, vision_proj (no bias).
@@ -139,7 +145,8 @@ def encode_vision(images, modality, state, arch):
     cls = state['clip_encoder.cls_token'].expand(B, -1, -1)
     x = torch.cat([cls, pe], dim=1) + state['clip_encoder.vision_pos_embed'].unsqueeze(0)
     for i in range(arch['vision_layers']):
-        x = vision_block(x, state, f'clip_encoder.vision_layers.{i}', modality, arch['vision_heads'], scaling)
+        x = vision_block(x, state, f'clip_encoder.vision_layers.{i}', modality, arch['vision_heads'], scaling,
+                         None if drop_scales is None else drop_scales[i])
     x0 = layer_norm(x[:, 0], state['clip_encoder.vision_ln_final.weight'], state['clip_encoder.vision_ln_final.bias'])
     return x0 @ state['clip_encoder.vision_proj.weight'].t()
 

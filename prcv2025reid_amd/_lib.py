@@ -56,7 +56,7 @@ class GemmArgs(C.Structure):
                 ('r_period', C.c_int32),
                 ('mask_r', C.c_int32), ('mask_period', C.c_int32), ('rows_per_img', C.c_int32),
                 ('c_group', C.c_int32), ('c_group_stride', C.c_int32), ('c_row_off', C.c_int32),
-                ('alpha', C.c_float)]
+                ('alpha', C.c_float), ('row_scale', C.c_void_p)]
 
 
 _libs = {}

@@ -84,6 +84,7 @@ class TrainingConfig:
     contrastive_weight: float = 0.0
     sdm_semantic_dim: int = 512
     sdm_num_heads: int = 8
+    sdm_dropout: float = 0.1   # not a reference config field: hard-coded in SemanticDisentanglementModule (models/model.py:35,43)
     sdm_temperature: float = 0.2
     sdm_init_temperature: float = 0.18
     sdm_final_temperature: float = 0.16

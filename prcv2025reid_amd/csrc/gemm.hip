@@ -22,6 +22,7 @@ struct GemmParams {
     const float* bias; const void* R; const bf16_t* aux;
     void* C; void* C2;
     const int32_t* img_mod;
+    const float* row_scale;
     int M, N, K, K2;
     int lda, ldb, lda2, ldb2, ldr, ldaux, ldc, ldc2;
     int k2_group_n;
@@ -150,6 +151,11 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
         float v[CW];
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = acc[MODE == 1 ? 2 * pc + (e >> 2) : pc][i][e & 3];
+        if (p.row_scale) {                                   // DropPath: the whole branch output of this sample, before the residual
+            const float rs = p.row_scale[(m < mlast ? m : mlast) / p.rows_per_img];
+#pragma unroll
+            for (int e = 0; e < CW; ++e) v[e] *= rs;
+        }
         if (has_r) {
 #pragma unroll
             for (int e = 0; e < CW; ++e) v[e] += rv[slot].v[e];
@@ -277,9 +283,10 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     REID_CHECK_ARG(a->mask_r == 0 || (a->img_mod && a->rows_per_img > 0 && a->mask_period > 0),
                    "reid_mer_gemm: modality mask needs img_mod, rows_per_img, mask_period");
     REID_CHECK_ARG(a->c_group == 0 || a->c_group_stride >= a->c_group, "reid_mer_gemm: c_group_stride");
+    REID_CHECK_ARG(!a->row_scale || a->rows_per_img > 0, "reid_mer_gemm: row_scale needs rows_per_img");
     GemmParams p;
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.A2 = (const bf16_t*)a->A2; p.B2 = (const bf16_t*)a->B2;
-    p.bias = a->bias; p.R = a->R; p.aux = (const bf16_t*)a->aux; p.C = a->C; p.C2 = a->C2; p.img_mod = a->img_mod;
+    p.bias = a->bias; p.R = a->R; p.aux = (const bf16_t*)a->aux; p.C = a->C; p.C2 = a->C2; p.img_mod = a->img_mod; p.row_scale = a->row_scale;
     p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->A2 ? a->K2 : 0;
     p.lda = a->lda; p.ldb = a->ldb; p.lda2 = a->lda2; p.ldb2 = a->ldb2; p.ldr = a->ldr; p.ldaux = a->ldaux;
     p.ldc = a->ldc; p.ldc2 = a->ldc2; p.k2_group_n = a->k2_group_n;

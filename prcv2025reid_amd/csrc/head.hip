@@ -445,8 +445,8 @@ __global__ void eltwise_kernel(int op, const float* __restrict__ x, const float*
 // Attention over S <= 8 tokens, head_dim 64, fp32 (nn.MultiheadAttention of FeatureFusion, model.py:152-155).
 // One wave per (sequence, head); lane = one of the 64 head dimensions; scores by wave reductions.
 __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __restrict__ qkv, int ld, const uint8_t* __restrict__ key_mask,
-                                                             float* __restrict__ out, int ldo, float* __restrict__ probs, int n_seq,
-                                                             int S, int heads) {
+                                                             const float* __restrict__ drop, float* __restrict__ out, int ldo,
+                                                             float* __restrict__ probs, int n_seq, int S, int heads) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_seq * heads) return;
@@ -474,14 +474,18 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __rest
         for (int j = 0; j < 8; ++j) { sc[j] = __expf(sc[j] - mx); den += sc[j]; }
         float o = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] /= den; o += sc[j] * v[j]; if (lane == j) pr[i * 8 + j] = sc[j]; }
+        for (int j = 0; j < 8; ++j) {
+            sc[j] /= den;
+            if (lane == j) pr[i * 8 + j] = sc[j];                                   // saved: the softmax output, before dropout
+            o += sc[j] * (drop ? drop[(size_t)item * 64 + i * 8 + j] : 1.f) * v[j];
+        }
         out[(size_t)(seq * S + i) * ldo + head * 64 + lane] = o;
     }
 }
 
 __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ probs,
-                                                             const float* __restrict__ dout, int ldo, float* __restrict__ dqkv, int lddq,
-                                                             int n_seq, int S, int heads) {
+                                                             const float* __restrict__ drop, const float* __restrict__ dout, int ldo,
+                                                             float* __restrict__ dqkv, int lddq, int n_seq, int S, int heads) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_seq * heads) return;
@@ -503,9 +507,10 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             p[j] = j < S ? pr[i * 8 + j] : 0.f;
-            dp[j] = wave_sum(go[i] * v[j]);
+            const float mj = drop ? drop[(size_t)item * 64 + i * 8 + j] : 1.f;     // out = sum_j (p_j m_j) v_j
+            dp[j] = wave_sum(go[i] * v[j]) * mj;
             dot += p[j] * dp[j];
-            dv[j] += p[j] * go[i];
+            dv[j] += p[j] * mj * go[i];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -699,20 +704,20 @@ extern "C" int reid_eltwise_f32(int32_t op, const float* x, const float* y, floa
     return REID_OK;
 }
 
-extern "C" int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, float* out, int32_t ldo, float* probs,
+extern "C" int reid_small_attn_fwd(const float* qkv, int32_t ld, const uint8_t* key_mask, const float* drop, float* out, int32_t ldo, float* probs,
                                    int32_t n_seq, int32_t S, int32_t heads, void* stream) {
     REID_CHECK_ARG(qkv && out && probs && n_seq > 0 && S >= 1 && S <= 8 && heads > 0 && ld >= 3 * heads * 64 && ldo >= heads * 64,
                    "reid_small_attn_fwd: bad args (S=%d must be 1..8)", S);
-    hipLaunchKernelGGL(small_attn_fwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, key_mask, out, ldo,
+    hipLaunchKernelGGL(small_attn_fwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, key_mask, drop, out, ldo,
                        probs, n_seq, S, heads);
     REID_CHECK_LAUNCH("reid_small_attn_fwd");
     return REID_OK;
 }
 
-extern "C" int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* dout, int32_t ldo, float* dqkv,
+extern "C" int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* probs, const float* drop, const float* dout, int32_t ldo, float* dqkv,
                                    int32_t lddqkv, int32_t n_seq, int32_t S, int32_t heads, void* stream) {
     REID_CHECK_ARG(qkv && probs && dout && dqkv && n_seq > 0 && S >= 1 && S <= 8 && heads > 0, "reid_small_attn_bwd: bad args");
-    hipLaunchKernelGGL(small_attn_bwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, probs, dout, ldo,
+    hipLaunchKernelGGL(small_attn_bwd_kernel, dim3((n_seq * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, qkv, ld, probs, drop, dout, ldo,
                        dqkv, lddqkv, n_seq, S, heads);
     REID_CHECK_LAUNCH("reid_small_attn_bwd");
     return REID_OK;

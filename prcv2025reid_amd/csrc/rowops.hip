@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      bf16_t* __restrict__ dxb, int lddx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int cols) {
+                                                     float* __restrict__ dbeta, int rows, int cols,
+                                                     const float* __restrict__ bscale, int rows_per_img) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
     }
     const float m1 = wave_sum(s1) / cols, m2 = wave_sum(s2) / cols;
+    const float bs = bscale ? bscale[xrow / rows_per_img] : 1.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 o += r;
             }
             *(f32x4*)(dx + xrow * lddx + c * 4) = o;
-            if (dxb) *(uint2*)(dxb + xrow * lddx + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            if (dxb) *(uint2*)(dxb + xrow * lddx + c * 4) = uint2{pack_bf16x2(o[0] * bs, o[1] * bs), pack_bf16x2(o[2] * bs, o[3] * bs)};
         }
     }
 }
@@ -257,18 +259,19 @@ extern "C" int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* ro
 extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
                                   const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
                                   const float* dres, float* dx, void* dx_bf16, int32_t lddx, float* dgamma, float* dbeta,
-                                  int32_t rows, int32_t cols, void* stream) {
+                                  int32_t rows, int32_t cols, const float* bf16_row_scale, int32_t rows_per_img, void* stream) {
     REID_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "reid_layernorm_bwd: null pointer");
+    REID_CHECK_ARG(!bf16_row_scale || rows_per_img > 0, "reid_layernorm_bwd: bf16_row_scale needs rows_per_img");
     REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_layernorm_bwd: cols=%d unsupported", cols);
     REID_CHECK_ARG(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "reid_layernorm_bwd: ld");
     dim3 g((rows + 3) / 4), b(256);
     hipStream_t s = (hipStream_t)stream;
     if (dy_dtype == REID_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx,
-                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols);
+                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx,
-                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols);
+                           (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img);
     REID_CHECK_LAUNCH("reid_layernorm_bwd");
     return REID_OK;
 }

@@ -124,6 +124,9 @@ class Engine:
         self._table = None
         self._side = None
         self._consts = {}
+        self._rng = torch.Generator(device=device)
+        self._rng.manual_seed(777)
+        self.pending_drop_scales = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.W = {}
 
@@ -193,8 +196,24 @@ class Engine:
             self.pack_lora(); self._lora_ver = lv
 
     # ------------------------------------------------------------------------------- vision forward
-    def vision_forward(self, groups: List[Tuple[int, torch.Tensor]], save: bool):
-        """groups: [(modality index, images f32 [n,3,H,W])] -> (features f32 [n_img, D], saved state)."""
+    def drop_path_scales(self, n_img: int, rate: float):
+        """Per layer (s_attn, s_mlp), each f32 [n_img] = floor(keep + U) / keep with keep = 1 - rate * l / (L - 1)
+        (DropPath, clip_backbone.py:137-141 with the per-block rates of :204); None where the rate is 0."""
+        L = self.arch['vision_layers']
+        out = []
+        for l in range(L):
+            p = rate * l / max(1, L - 1)
+            if p <= 0.0:
+                out.append((None, None)); continue
+            keep = 1.0 - p
+            u = torch.rand(2, n_img, device=self.dev, generator=self._rng)
+            sc = torch.floor(u + keep) / keep
+            out.append((sc[0].contiguous(), sc[1].contiguous()))
+        return out
+
+    def vision_forward(self, groups: List[Tuple[int, torch.Tensor]], save: bool, drop_scales=None):
+        """groups: [(modality index, images f32 [n,3,H,W])] -> (features f32 [n_img, D], saved state).
+        ``drop_scales``: per layer (s_attn, s_mlp) per-image DropPath factors or None."""
         a, P, W, lay = self.arch, self.P, self.W, self.lay
         dev = self.dev
         S, d, ff, Rp, r = self.S, lay.d, lay.ff, lay.Rp, lay.r
@@ -247,8 +266,9 @@ class Engine:
             To = new('To', (M, Rp), b16)
             ops.gemm(o, pk(l, 'out', 'A'), To, **mk)
             xm = new('xm', (M, d), f32)
+            sa, sm_ = (None, None) if drop_scales is None else drop_scales[l]
             ops.gemm(o, W[('v', l, 'out')], xm, A2=To, B2=pk(l, 'out', 'B'), K2=Rp,
-                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=x)
+                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=x, row_scale=sa, rows_per_img=S)
             h2 = new('h2', (M, d), b16); mean2 = new('m2', (M,), f32); rstd2 = new('r2', (M,), f32)
             ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
             T1 = new('T1', (M, Rp), b16)
@@ -261,10 +281,10 @@ class Engine:
             ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mk)
             xn = torch.empty(M, d, **f32) if save else new('xn' + str(l & 1), (M, d), f32)
             ops.gemm(g, W[('v', l, 'fc2')], xn, A2=T2, B2=pk(l, 'fc2', 'B'), K2=Rp,
-                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm)
+                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=S)
             if save:
                 saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
-                                  mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2))
+                                  mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2, sa=sa, sm=sm_))
             x = xn
         idx = self._const(('cls_idx', n_img, S), lambda: torch.arange(n_img, dtype=torch.int32) * S)
         cls_h = torch.empty(n_img, d, **b16); mf = torch.empty(n_img, **f32); rf = torch.empty(n_img, **f32)
@@ -299,8 +319,9 @@ class Engine:
         dcls = torch.empty(n_img, d, **b16)
         ops.gemm(dfb, W['vprojT'], dcls)
         dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
+        # dxb always holds the gradient ENTERING the next residual branch: dx times that branch's DropPath factor
         ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
-                          row_index=st['idx'])
+                          row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S)
         # reusable scratch (one U per linear: the side stream still reads it while the next skinny GEMM runs)
         U2 = torch.empty(M, Rp, **b16); U1 = torch.empty(M, Rp, **b16); Uo = torch.empty(M, Rp, **b16)
         Uq = torch.empty(M, 3 * Rp, **b16)
@@ -338,7 +359,8 @@ class Engine:
             fork((du, s['T1'], gB(l, 'fc1')), (U1, s['h2'], gA(l, 'fc1')))
             ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U1, B2=pk(l, 'fc1', 'AT'), K2=Rp)
             # ---- LN2
-            ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx)
+            ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx,
+                              bf16_row_scale=s['sa'], rows_per_img=S)
             # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
             ops.gemm(dxmb, pk(l, 'out', 'BT'), Uo, **mk)
             fork((dxmb, s['To'], gB(l, 'out')), (Uo, s['o'], gA(l, 'out')))
@@ -355,7 +377,8 @@ class Engine:
             ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
             # ---- LN1 (rewrites dxb, and the next layer rewrites du/dxmb/dqkv/U*: the side stream must be done with them)
             join()
-            ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm)
+            ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm,
+                              bf16_row_scale=st['layers'][l - 1]['sm'] if l > 0 else None, rows_per_img=S)
         if scale_t is not None:
             grad.mul_(1.0 / scale_t)
         return grad
@@ -403,7 +426,9 @@ class VisionEncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine: Engine, mods: Tuple[int, ...], lora_arena: torch.Tensor, *images):
         need = bool(ctx.needs_input_grad[2])
-        feats, st = engine.vision_forward(list(zip(mods, images)), save=need)
+        scales = engine.pending_drop_scales if need else None     # set by the model for this call (training + drop_path > 0)
+        engine.pending_drop_scales = None
+        feats, st = engine.vision_forward(list(zip(mods, images)), save=need, drop_scales=scales)
         ctx.engine = engine
         ctx.st = st
         ctx.n_images = len(images)

@@ -123,6 +123,21 @@ class AddFn(torch.autograd.Function):
         return g, g
 
 
+class MulFn(torch.autograd.Function):
+    """y = x * m with a constant multiplier tensor m (dropout masks 0 or 1/keep): nn.Dropout / DropPath-style scaling."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        m = m.contiguous().float()
+        ctx.save_for_backward(m)
+        return ops.eltwise('mul', x.contiguous().float(), m)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return ops.eltwise('mul', g.contiguous().float(), m), None
+
+
 class ActFn(torch.autograd.Function):
     """relu / gelu (exact erf form) with the matching derivative kernels."""
 
@@ -211,23 +226,25 @@ class SmallAttnFn(torch.autograd.Function):
     """softmax(q k^T / 8 + key padding) v over S <= 8 tokens (nn.MultiheadAttention core, head_dim 64), fp32."""
 
     @staticmethod
-    def forward(ctx, qkv, key_mask, n_seq: int, S: int, heads: int):
+    def forward(ctx, qkv, key_mask, n_seq: int, S: int, heads: int, drop=None):
+        """``drop``: optional f32 [n_seq, heads, 8, 8] attention-dropout multipliers (0 or 1/keep)."""
         qkv = qkv.contiguous().float()
         d = heads * 64
         out = torch.empty(n_seq * S, d, device=qkv.device)
         probs = torch.zeros(n_seq * heads * 64, device=qkv.device)
-        ops.small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads)
-        ctx.save_for_backward(qkv, probs)
+        drop = None if drop is None else drop.contiguous().float()
+        ops.small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads, drop=drop)
+        ctx.save_for_backward(qkv, probs, drop)
         ctx.dims = (n_seq, S, heads)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, probs = ctx.saved_tensors
+        qkv, probs, drop = ctx.saved_tensors
         n_seq, S, heads = ctx.dims
         dqkv = torch.empty_like(qkv)
-        ops.small_attn_bwd(qkv, probs, g.contiguous().float(), dqkv, n_seq, S, heads)
-        return dqkv, None, None, None, None
+        ops.small_attn_bwd(qkv, probs, g.contiguous().float(), dqkv, n_seq, S, heads, drop=drop)
+        return dqkv, None, None, None, None, None
 
 
 class MaskedMeanFn(torch.autograd.Function):

@@ -14,9 +14,12 @@ Deliberate differences (documented in DESIGN.md):
     ``input_ids``/``attention_mask`` (pre-tokenised, keeps the tokenizer off the hot path);
   * all LoRA adapters live in ONE flat fp32 parameter (``clip_encoder.vision_layers.loras.arena``);
     ``state_dict()`` still emits the reference's per-adapter keys, and ``load_state_dict`` accepts them;
-  * stochastic regularisers (DropPath, dropouts, batch-level modality dropout, models/model.py:435-473,
-    clip_backbone.py:126-142) are not applied; the reference's train/eval asymmetry (SDM module only in
-    train mode, models/model.py:395-399) IS kept;
+  * the stochastic regularisers of the training forward ARE applied in train mode -- DropPath (clip_backbone.py:126-142),
+    the dropouts of the SDM module / fusion block / BN-neck (models/model.py:35,43,95,104,106,221) and the batch-level
+    modality dropout (models/model.py:434-474) -- from this package's own generators (the random streams cannot coincide
+    with torch's: the reference draws per modality pass, here the modalities run packed); modality dropout masks the dropped
+    modality's fusion slot instead of removing it from the list (same function, static shapes); the reference's train/eval
+    asymmetry (SDM module only in train mode, models/model.py:395-399) is kept;
   * gradients are implemented for what the reference trains by default (train.py:1418-1425: LoRA,
     bn_neck, null_tokens) plus the torch-side head modules; asking for gradients of frozen-by-default
     backbone tensors raises NotImplementedError instead of silently returning none.
@@ -31,7 +34,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .config import arch_of
 from .engine import Engine, LoraLayout, VisionEncodeFn
-from .head import (ActFn, AddFn, BNNeckFn, CrossEntropyLSFn, LayerNormF32Fn, LinearF32Fn, LinearNdF32Fn, MaskedMeanFn,
+from .head import (MulFn, ActFn, AddFn, BNNeckFn, CrossEntropyLSFn, LayerNormF32Fn, LinearF32Fn, LinearNdF32Fn, MaskedMeanFn,
                    NanToNumFn, SDMFn, SmallAttnFn)
 from .tokenizer import load_tokenizer
 from .weights import param_spec, seeded_tensor, is_dead_key
@@ -107,6 +110,19 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self._ref[LORA_PARAM_NAME] = self.lora_arena
         self.engine = Engine(self.arch, self._ref, self.lora_arena, dev)
         self._plans = {}
+        # Stochastic regularisers of the reference's training forward (all inactive in eval mode):
+        #   DropPath in the vision blocks (clip_backbone.py:137-141,204), dropout in the SDM module (hard-coded 0.1: model.py:35,43),
+        #   in the fusion block (fusion_dropout: model.py:95,104,106), before the classifier (dropout_rate: model.py:200,221),
+        #   and batch-level modality dropout (model.py:434-474).
+        # Head-level masks come from a generator seeded identically on every data-parallel rank (the head is evaluated
+        # redundantly on the gathered global batch, so its random masks must agree); DropPath uses the engine's own generator.
+        self.drop_path = float(getattr(config, 'drop_path', 0.0))
+        self.dropout_rate = float(getattr(config, 'dropout_rate', 0.5))
+        self.fusion_dropout = float(getattr(config, 'fusion_dropout', 0.1))
+        self.sdm_dropout = float(getattr(config, 'sdm_dropout', 0.1))
+        self._rng_head = torch.Generator(device=dev); self._rng_head.manual_seed(int(seed) + 12345)
+        self._rng_host = torch.Generator(); self._rng_host.manual_seed(int(seed) + 54321)
+        self.engine._rng.manual_seed(int(seed) + 777)
         self.tokenizer = load_tokenizer(getattr(config, 'clip_model_name', ''), self.arch['text_vocab'],
                                         self.arch['text_bos_id'], self.arch['text_eos_id'], self.arch['text_max_len'])
         # facades so callers written against the reference's attribute paths keep working
@@ -252,16 +268,40 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         ids, am = self._tokens(texts)
         return self.engine.text_forward(ids, am)
 
+    def seed_stochastic(self, seed: int, rank: int = 0):
+        """Reseed the regularisers' generators (head masks identical on every rank, DropPath per rank)."""
+        self._rng_head.manual_seed(int(seed) + 12345)
+        self._rng_host.manual_seed(int(seed) + 54321)
+        self.engine._rng.manual_seed(int(seed) + 777 + 1000003 * int(rank))
+
+    def _keep_mask(self, shape, p: float) -> torch.Tensor:
+        """Dropout multipliers: 0 with probability p, else 1 / (1 - p)."""
+        u = torch.rand(shape, device=self._rng_head.device, generator=self._rng_head)
+        return (u >= p).float() / (1.0 - p)
+
+    def _dropout(self, x, p: float):
+        if not self.training or p <= 0.0:
+            return x
+        return MulFn.apply(x, self._keep_mask(tuple(x.shape), p))
+
     # ------------------------------------------------------------------ head modules ([B,512] / [B,M,512], fp32 HIP kernels)
     def _sdm_module(self, x):
         """SemanticDisentanglementModule.forward, models/model.py:57-77 (length-1 MHA == out_proj(v_proj(x)))."""
         P, D = self._ref, self.fusion_dim
         lin = LinearNdF32Fn.apply
         wv = P['sdm_module.semantic_attn.in_proj_weight'][2 * D:]; bv = P['sdm_module.semantic_attn.in_proj_bias'][2 * D:]
-        a = lin(lin(x, wv, bv), P['sdm_module.semantic_attn.out_proj.weight'], P['sdm_module.semantic_attn.out_proj.bias'])
+        v = lin(x, wv, bv)
+        if self.training and self.sdm_dropout > 0:
+            # nn.MultiheadAttention(dropout=0.1) on a length-1 sequence: the single attention weight (= 1) of every
+            # (sample, head) is dropped or scaled by 1/keep, i.e. that head's 64 value channels are
+            H = self.arch['sdm_num_heads']
+            m = self._keep_mask((x.shape[0], H, 1), self.sdm_dropout).expand(x.shape[0], H, D // H).reshape(x.shape[0], D)
+            v = MulFn.apply(v, m)
+        a = lin(v, P['sdm_module.semantic_attn.out_proj.weight'], P['sdm_module.semantic_attn.out_proj.bias'])
         y = lin(AddFn.apply(x, a), P['sdm_module.semantic_proj.0.weight'], P['sdm_module.semantic_proj.0.bias'])
         y = LayerNormF32Fn.apply(y, P['sdm_module.semantic_proj.1.weight'], P['sdm_module.semantic_proj.1.bias'], 1e-5)
-        return lin(ActFn.apply(y, 'relu'), P['sdm_module.semantic_proj.4.weight'], P['sdm_module.semantic_proj.4.bias'])
+        y = self._dropout(ActFn.apply(y, 'relu'), self.sdm_dropout)
+        return lin(y, P['sdm_module.semantic_proj.4.weight'], P['sdm_module.semantic_proj.4.bias'])
 
     def _fusion(self, features: List[torch.Tensor], masks: Optional[List[torch.Tensor]] = None):
         """FeatureFusion.forward, models/model.py:113-183.  stack / where / cat below only move data; every arithmetic
@@ -288,17 +328,46 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             pad = torch.cat([(pad[:, 0] & ~dead).unsqueeze(1), pad[:, 1:]], dim=1)
             km = (~pad).to(torch.uint8).contiguous()
         qkv = lin(x.reshape(B * M, D), P['feature_fusion.multihead_attn.in_proj_weight'], P['feature_fusion.multihead_attn.in_proj_bias'])
-        a = SmallAttnFn.apply(qkv, km, B, M, heads)
+        drop = None
+        if self.training and self.fusion_dropout > 0:
+            drop = self._keep_mask((B, heads, 8, 8), self.fusion_dropout)            # attention-probability dropout (model.py:95)
+        a = SmallAttnFn.apply(qkv, km, B, M, heads, drop)
         a = lin(a, P['feature_fusion.multihead_attn.out_proj.weight'], P['feature_fusion.multihead_attn.out_proj.bias'])
         y = ln(AddFn.apply(x.reshape(B * M, D), a), P['feature_fusion.norm1.weight'], P['feature_fusion.norm1.bias'], 1e-5)
         m = ln(y, P['feature_fusion.mlp.0.weight'], P['feature_fusion.mlp.0.bias'], 1e-5)
-        m = ActFn.apply(lin(m, P['feature_fusion.mlp.1.weight'], P['feature_fusion.mlp.1.bias']), 'gelu')
-        m = lin(m, P['feature_fusion.mlp.4.weight'], P['feature_fusion.mlp.4.bias'])
+        m = self._dropout(ActFn.apply(lin(m, P['feature_fusion.mlp.1.weight'], P['feature_fusion.mlp.1.bias']), 'gelu'), self.fusion_dropout)
+        m = self._dropout(lin(m, P['feature_fusion.mlp.4.weight'], P['feature_fusion.mlp.4.bias']), self.fusion_dropout)
         z = ln(AddFn.apply(y, m), P['feature_fusion.norm2.weight'], P['feature_fusion.norm2.bias'], 1e-5)
         z = NanToNumFn.apply(z).view(B, M, D)
         if sm is None:
             sm = torch.ones(B, M, device=x.device)
         return MaskedMeanFn.apply(z, sm)
+
+    def _modality_dropout(self, names: List[str], masks: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Batch-level modality dropout, models/model.py:434-474, on the masks that enter the fusion block.
+
+        The reference removes a dropped modality from the list it fuses; masking its slot for every sample is the same
+        function (a masked slot is no key, and its own output is excluded by the masked mean), keeps the shapes static and
+        lets the reference's safety rule -- cancel the whole draw if it would leave a sample without any valid modality --
+        run on the device without a host read-back.  'vis' is never dropped; one host draw per other modality, in order
+        (``torch.rand(1).item() > p`` keeps), as in the reference; inactive while epoch <= modality_dropout_warmup_epochs."""
+        cfg = self.config
+        p = float(getattr(cfg, 'modality_dropout', 0.0))
+        min_mod = int(getattr(cfg, 'min_modalities', 1))
+        if self.current_epoch <= int(getattr(cfg, 'modality_dropout_warmup_epochs', 3)):
+            p = 0.0
+        if p <= 0.0 or len(names) <= min_mod:
+            return masks
+        keep = [m == 'vis' or float(torch.rand(1, generator=self._rng_host)) > p for m in names]
+        if all(keep) or sum(keep) < min_mod:
+            return masks
+        dev = masks[0].device
+        kv = self.engine._const(('moddrop', tuple(keep)), lambda: torch.tensor([1.0 if k else 0.0 for k in keep]))
+        stacked = torch.stack([m.to(dev).float() for m in masks], dim=1)             # [B, M]
+        dropped = stacked * kv.view(1, -1)
+        ok = ((dropped > 0).any(dim=1)).all()                                        # every sample keeps >= 1 valid modality
+        final = torch.where(ok, dropped, stacked)
+        return [final[:, i].contiguous() for i in range(len(masks))]
 
     def _plan(self, images, modality_masks, B):
         """{modality: (kind 'all' | 'some' | 'none', device row indices or None, device mask f32 [B])}."""
@@ -371,6 +440,8 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
                     order.append((m, None if kind == 'all' else sel_idx, mask_dev))
         feats = None
         if groups:
+            if self.training and self.drop_path > 0 and torch.is_grad_enabled():
+                self.engine.pending_drop_scales = self.engine.drop_path_scales(sum(g[1].shape[0] for g in groups), self.drop_path)
             feats = VisionEncodeFn.apply(self.engine, tuple(g[0] for g in groups), self.lora_arena, *[g[1] for g in groups])
         start = 0
         for m, idx, mask in order:
@@ -397,6 +468,8 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             raw, fmask = gather_fn(raw, fmask)
         sem = OrderedDict((m, self._sdm_module(f) if self.training else f) for m, f in raw.items())
         flist = list(sem.values()); mlist = [fmask[m] for m in sem]
+        if self.training:
+            mlist = self._modality_dropout(list(sem.keys()), mlist)
         fused = flist[0] if len(flist) == 1 else self._fusion(flist, mlist)
         out = {'features': fused, 'raw_modality_features': raw, 'modality_features': sem}
         if self.bn_neck is not None:
@@ -404,7 +477,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             bnf = BNNeckFn.apply(fused, P['bn_neck.bn.weight'], P['bn_neck.bn.bias'], self._bufs['bn_neck.bn.running_mean'],
                                  self._bufs['bn_neck.bn.running_var'], self.training, 0.1, 1e-5)
             out['bn_features'] = bnf
-            out['logits'] = LinearF32Fn.apply(bnf, P['bn_neck.classifier.weight'], None)
+            out['logits'] = LinearF32Fn.apply(self._dropout(bnf, self.dropout_rate), P['bn_neck.classifier.weight'], None)
         if return_features:
             out['intermediate_features'] = {'raw_modality': raw, 'semantic_modality': sem, 'fused': fused}
         out['feature_masks'] = fmask

@@ -30,7 +30,7 @@ def gemm_profile_end():
 
 def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None, r_period=0, aux=None,
          C2=None, act='none', img_mod=None, mask_r=0, mask_period=0, rows_per_img=0,
-         c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None):
+         c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None, row_scale=None):
     """C_out = epilogue(A @ B.T + A2 @ B2.T + bias); see reid_mer_gemm in include/reid_hip.h."""
     a = GemmArgs()
     a.A, a.B, a.C = ptr(A), ptr(B), ptr(C_out)
@@ -56,6 +56,8 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         a.img_mod = ptr(img_mod); a.mask_r = mask_r; a.mask_period = mask_period; a.rows_per_img = rows_per_img
     a.c_group, a.c_group_stride, a.c_row_off = c_group, c_group_stride, c_row_off
     a.alpha = alpha
+    if row_scale is not None:
+        a.row_scale = ptr(row_scale); a.rows_per_img = rows_per_img
     if _gemm_profile is not None and a.N > 96:   # mer_gemm_kernel<128,128,2,2> (dominant); skinny LoRA projections use other tiles
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -101,7 +103,7 @@ def ln_profile_end():
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=None, dres=None, row_index=None, dgamma=None, dbeta=None,
-                  rows=None):
+                  rows=None, bf16_row_scale=None, rows_per_img=0):
     rows = (row_index.shape[0] if row_index is not None else x.shape[0]) if rows is None else rows
     if _ln_profile is not None and rows >= 4096 and row_index is None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -112,13 +114,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=None, dres=None, row_ind
         e0.record()
         check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
                                        ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
-                                       ptr(dbeta), rows, x.shape[1], stream_ptr()))
+                                       ptr(dbeta), rows, x.shape[1], ptr(bf16_row_scale), rows_per_img, stream_ptr()))
         e1.record()
         _ln_profile.append((nbytes, e0, e1))
         return
     check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
                                    ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
-                                   ptr(dbeta), rows, x.shape[1], stream_ptr()))
+                                   ptr(dbeta), rows, x.shape[1], ptr(bf16_row_scale), rows_per_img, stream_ptr()))
 
 
 def patch_im2col(images, patches, patch, cin):
@@ -266,14 +268,14 @@ def eltwise(op, x, y=None, out=None, alpha=1.0):
     return out
 
 
-def small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads):
-    check(lib().reid_small_attn_fwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), out.stride(0), ptr(probs), n_seq, S, heads,
-                                    stream_ptr()))
+def small_attn_fwd(qkv, key_mask, out, probs, n_seq, S, heads, drop=None):
+    check(lib().reid_small_attn_fwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(drop), ptr(out), out.stride(0), ptr(probs), n_seq, S,
+                                    heads, stream_ptr()))
 
 
-def small_attn_bwd(qkv, probs, dout, dqkv, n_seq, S, heads):
-    check(lib().reid_small_attn_bwd(ptr(qkv), qkv.stride(0), ptr(probs), ptr(dout), dout.stride(0), ptr(dqkv), dqkv.stride(0),
-                                    n_seq, S, heads, stream_ptr()))
+def small_attn_bwd(qkv, probs, dout, dqkv, n_seq, S, heads, drop=None):
+    check(lib().reid_small_attn_bwd(ptr(qkv), qkv.stride(0), ptr(probs), ptr(drop), ptr(dout), dout.stride(0), ptr(dqkv),
+                                    dqkv.stride(0), n_seq, S, heads, stream_ptr()))
 
 
 def masked_mean(x, mask, out, B, M, D, backward=False):

@@ -27,7 +27,7 @@ def case_config(meta, device='cpu'):
         vision_mlp_dim=int(meta['vision_mlp_dim']), text_layers=int(meta['text_layers']),
         text_mlp_dim=int(meta['text_mlp_dim']), text_vocab=int(meta['text_vocab']),
         text_eos_id=int(meta['text_eos_id']), text_bos_id=int(meta['text_bos_id']),
-        drop_path=0.0, modality_dropout=0.0, dropout_rate=0.0, fusion_dropout=0.0)
+        drop_path=0.0, modality_dropout=0.0, dropout_rate=0.0, fusion_dropout=0.0, sdm_dropout=0.0)
 
 
 def case_inputs(meta):
