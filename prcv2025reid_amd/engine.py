@@ -127,6 +127,7 @@ class Engine:
         self._rng = torch.Generator(device=device)
         self._rng.manual_seed(777)
         self.pending_drop_scales = None
+        self.text_backward_ready = False
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.W = {}
 
@@ -292,12 +293,23 @@ class Engine:
                           row_index=idx)
         feats = torch.empty(n_img, a['fusion_dim'], **f32)
         ops.gemm(cls_h, W['vproj'], feats)
-        state = dict(layers=saved, x_final=x, idx=idx, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img) if save else None
+        state = dict(layers=saved, x_final=x, idx=idx, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
+                     groups=groups) if save else None
         return feats, state
 
     # ------------------------------------------------------------------------------- vision backward
-    def vision_backward(self, st, dfeat: torch.Tensor) -> torch.Tensor:
-        """dfeat f32 [n_img, D] -> fp32 gradient of the LoRA arena (same layout as the arena)."""
+    def vision_dense_keys(self) -> List[str]:
+        """Reference keys of the vision backbone tensors (everything of clip_encoder that is not the text tower, its
+        projection, or a LoRA adapter), in a fixed order: the non-LoRA inputs / gradient outputs of VisionEncodeFn."""
+        tp = 'clip_encoder.clip_model.'
+        return [k for k in self.P if k.startswith('clip_encoder.') and not k.startswith(tp) and '.loras.' not in k
+                and k != 'clip_encoder.text_proj.weight' and self.P[k] is not self.lora_arena]
+
+    def vision_backward(self, st, dfeat: torch.Tensor, want_dense: bool = False):
+        """dfeat f32 [n_img, D] -> fp32 gradient of the LoRA arena (same layout as the arena); with ``want_dense`` also a
+        dict {reference key: fp32 gradient} for the backbone tensors (weights by reduce-over-rows GEMMs dY^T X, biases as
+        column sums of dY, LayerNorm affine pairs from the LN backward kernel, position / class embeddings and the patch
+        convolutions from the gradient of the embedded sequence) -- the reference's ``freeze_backbone=False`` mode."""
         a, P, W, lay = self.arch, self.P, self.W, self.lay
         dev = self.dev
         S, d, ff, Rp, r = self.S, lay.d, lay.ff, lay.Rp, lay.r
@@ -319,9 +331,31 @@ class Engine:
         dcls = torch.empty(n_img, d, **b16)
         ops.gemm(dfb, W['vprojT'], dcls)
         dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
+        dense = {} if want_dense else None
+        ones8 = torch.ones(M, 8, **b16) if want_dense else None
+
+        def wgrad(dY, X):                                   # dW [N, K] = dY^T X  (rows reduced on the matrix cores)
+            out = torch.empty(dY.shape[1], X.shape[1], **f32)
+            ops.gemm_tn(dY, X, out)
+            return out
+
+        def colsum(dY):                                     # db [N] = column sums of dY (same kernel against a block of ones)
+            out = torch.empty(dY.shape[1], 8, **f32)
+            ops.gemm_tn(dY, ones8[:dY.shape[0]], out)
+            return out[:, 0].contiguous()
+
+        def ln_grads(key):
+            if not want_dense:
+                return None, None
+            dense[key + '.weight'] = torch.zeros(d, **f32); dense[key + '.bias'] = torch.zeros(d, **f32)
+            return dense[key + '.weight'], dense[key + '.bias']
+
+        if want_dense:
+            dense[ce + 'vision_proj.weight'] = wgrad(dfb, st['cls_h'])
+        dgf, dbf = ln_grads(ce + 'vision_ln_final')
         # dxb always holds the gradient ENTERING the next residual branch: dx times that branch's DropPath factor
         ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
-                          row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S)
+                          row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S, dgamma=dgf, dbeta=dbf)
         # reusable scratch (one U per linear: the side stream still reads it while the next skinny GEMM runs)
         U2 = torch.empty(M, Rp, **b16); U1 = torch.empty(M, Rp, **b16); Uo = torch.empty(M, Rp, **b16)
         Uq = torch.empty(M, 3 * Rp, **b16)
@@ -354,17 +388,27 @@ class Engine:
             ops.gemm(dxb, pk(l, 'fc2', 'BT'), U2, **mk)
             fork((dxb, s['T2'], gB(l, 'fc2')), (U2, s['g'], gA(l, 'fc2')))
             ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U2, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
+            if want_dense:
+                dense[lp + 'mlp.fc2.shared_linear.weight'] = wgrad(dxb, s['g'])
+                dense[lp + 'mlp.fc2.shared_linear.bias'] = colsum(dxb)
             # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
             ops.gemm(du, pk(l, 'fc1', 'BT'), U1, **mk)
             fork((du, s['T1'], gB(l, 'fc1')), (U1, s['h2'], gA(l, 'fc1')))
             ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U1, B2=pk(l, 'fc1', 'AT'), K2=Rp)
+            if want_dense:
+                dense[lp + 'mlp.fc1.shared_linear.weight'] = wgrad(du, s['h2'])
+                dense[lp + 'mlp.fc1.shared_linear.bias'] = colsum(du)
             # ---- LN2
+            dg2, db2 = ln_grads(lp + 'ln2')
             ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx,
-                              bf16_row_scale=s['sa'], rows_per_img=S)
+                              bf16_row_scale=s['sa'], rows_per_img=S, dgamma=dg2, dbeta=db2)
             # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
             ops.gemm(dxmb, pk(l, 'out', 'BT'), Uo, **mk)
             fork((dxmb, s['To'], gB(l, 'out')), (Uo, s['o'], gA(l, 'out')))
             ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=Uo, B2=pk(l, 'out', 'AT'), K2=Rp)
+            if want_dense:
+                dense[lp + 'attn.out_proj.shared_linear.weight'] = wgrad(dxmb, s['o'])
+                dense[lp + 'attn.out_proj.shared_linear.bias'] = colsum(dxmb)
             # ---- attention
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
@@ -375,13 +419,48 @@ class Engine:
             fork(*[(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d]) for g in range(3)],
                  (Uq, s['h'], gA(l, 'qkv')))
             ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
+            if want_dense:
+                gw = wgrad(dqkv, s['h']); gb_ = colsum(dqkv)
+                for gi, nm in enumerate('qkv'):
+                    dense[lp + f'attn.{nm}_proj.shared_linear.weight'] = gw[gi * d:(gi + 1) * d]
+                    dense[lp + f'attn.{nm}_proj.shared_linear.bias'] = gb_[gi * d:(gi + 1) * d]
             # ---- LN1 (rewrites dxb, and the next layer rewrites du/dxmb/dqkv/U*: the side stream must be done with them)
             join()
+            dg1, db1 = ln_grads(lp + 'ln1')
             ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm,
-                              bf16_row_scale=st['layers'][l - 1]['sm'] if l > 0 else None, rows_per_img=S)
+                              bf16_row_scale=st['layers'][l - 1]['sm'] if l > 0 else None, rows_per_img=S, dgamma=dg1, dbeta=db1)
+        if want_dense:
+            # embedded sequence x0[img, t] = (cls | patch_t) + pos[t]: dx now holds d loss / d x0
+            ones_r = torch.ones(1, n_img, **f32)
+            dpos = torch.empty(1, S * d, **f32)
+            ops.sgemm(ones_r, dx.view(n_img, S * d), dpos)
+            dpos = dpos.view(S, d)
+            dense[ce + 'vision_pos_embed'] = dpos
+            dense[ce + 'cls_token'] = dpos[0].reshape(1, 1, d).clone()
+            start = 0
+            acc_w, acc_b = {}, {}
+            for mu, img in st['groups']:
+                m = lay.vmods[mu]
+                n = img.shape[0]
+                wpe = W[('pe', m)]
+                cin = wpe.shape[1] // (a['patch_size'] ** 2)
+                patches = torch.empty(n * (S - 1), wpe.shape[1], **b16)
+                ops.patch_im2col(img.contiguous(), patches, a['patch_size'], cin)
+                dP = ops.to_bf16(dx.view(n_img, S, d)[start:start + n, 1:, :].reshape(n * (S - 1), d).contiguous())
+                gw = wgrad(dP, patches); gb_ = colsum(dP)
+                kw, kb = f'{ce}patch_embeds.{m}.proj.weight', f'{ce}patch_embeds.{m}.proj.bias'
+                acc_w[kw] = gw if kw not in acc_w else acc_w[kw] + gw
+                acc_b[kb] = gb_ if kb not in acc_b else acc_b[kb] + gb_
+                start += n
+            for k, v in acc_w.items():
+                dense[k] = v.view(P[k].shape)
+            dense.update(acc_b)
         if scale_t is not None:
             grad.mul_(1.0 / scale_t)
-        return grad
+            if want_dense:
+                for k in dense:
+                    dense[k] = dense[k] * (1.0 / scale_t)
+        return (grad, dense) if want_dense else grad
 
     # ------------------------------------------------------------------------------- text forward
     def text_forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
@@ -421,22 +500,34 @@ class Engine:
 
 
 class VisionEncodeFn(torch.autograd.Function):
-    """Autograd boundary of the vision executor: inputs (LoRA arena) -> per-image features."""
+    """Autograd boundary of the vision executor: (LoRA arena, images, [backbone tensors]) -> per-image features.
+    ``dense`` = the tensors of ``engine.vision_dense_keys()`` in that order when the backbone trains (freeze_backbone=False),
+    else empty: the default path carries no extra inputs."""
 
     @staticmethod
-    def forward(ctx, engine: Engine, mods: Tuple[int, ...], lora_arena: torch.Tensor, *images):
-        need = bool(ctx.needs_input_grad[2])
+    def forward(ctx, engine: Engine, mods: Tuple[int, ...], lora_arena: torch.Tensor, n_images: int, *tensors):
+        images, dense = tensors[:n_images], tensors[n_images:]
+        need_dense = any(ctx.needs_input_grad[4 + n_images + i] for i in range(len(dense)))
+        need = bool(ctx.needs_input_grad[2]) or need_dense
         scales = engine.pending_drop_scales if need else None     # set by the model for this call (training + drop_path > 0)
         engine.pending_drop_scales = None
         feats, st = engine.vision_forward(list(zip(mods, images)), save=need, drop_scales=scales)
         ctx.engine = engine
         ctx.st = st
-        ctx.n_images = len(images)
+        ctx.n_images = n_images
+        ctx.n_dense = len(dense)
+        ctx.need_dense = need_dense
         return feats
 
     @staticmethod
     def backward(ctx, dfeat):
         _lib.set_flavor(ctx.engine.flavor)
-        grad = ctx.engine.vision_backward(ctx.st, dfeat.contiguous().float())
+        res = ctx.engine.vision_backward(ctx.st, dfeat.contiguous().float(), want_dense=ctx.need_dense)
         ctx.st = None
-        return (None, None, grad) + (None,) * ctx.n_images
+        if ctx.need_dense:
+            grad, dense = res
+            keys = ctx.engine.vision_dense_keys()
+            dgr = tuple(dense.get(k) if ctx.needs_input_grad[4 + ctx.n_images + i] else None for i, k in enumerate(keys))
+        else:
+            grad, dgr = res, (None,) * ctx.n_dense
+        return (None, None, grad, None) + (None,) * ctx.n_images + dgr

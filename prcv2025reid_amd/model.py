@@ -240,12 +240,18 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
 
     def _check_trainable(self):
         for k, p in self._ref.items():
-            if p.requires_grad and k != LORA_PARAM_NAME and k.startswith('clip_encoder.'):
-                raise NotImplementedError(
-                    f'gradient of {k} requested: this build implements the reference default '
-                    '(train.py:1418-1425: only loras / bn_neck / null_tokens train; head modules via torch). '
-                    'Freeze the backbone: for n,p in model.named_parameters(): p.requires_grad = '
-                    '("loras" in n or "bn_neck" in n or "null_tokens" in n)')
+            if p.requires_grad and k.startswith('clip_encoder.clip_model.text_model.') and not self.engine.text_backward_ready:
+                raise NotImplementedError(f'gradient of {k} requested: the text tower has no backward pass in this build')
+
+    def _vision_apply(self, mods, images):
+        """VisionEncodeFn with the backbone tensors as extra autograd inputs only when one of them trains
+        (freeze_backbone=False); the reference default (train.py:1418-1425) passes none."""
+        dense = []
+        if torch.is_grad_enabled():
+            keys = self.engine.vision_dense_keys()
+            if any(self._ref[k].requires_grad for k in keys):
+                dense = [self._ref[k] for k in keys]
+        return VisionEncodeFn.apply(self.engine, tuple(mods), self.lora_arena, len(images), *images, *dense)
 
     # ------------------------------------------------------------------ encoders
     def _tokens(self, texts):
@@ -259,7 +265,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         mu = self.vision_modalities.index(modality)
-        return VisionEncodeFn.apply(self.engine, (mu,), self.lora_arena, images.to(self.device).float())
+        return self._vision_apply((mu,), [images.to(self.device).float()])
 
     def encode_text(self, texts) -> torch.Tensor:
         """clip_backbone.py:288-313."""
@@ -442,7 +448,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         if groups:
             if self.training and self.drop_path > 0 and torch.is_grad_enabled():
                 self.engine.pending_drop_scales = self.engine.drop_path_scales(sum(g[1].shape[0] for g in groups), self.drop_path)
-            feats = VisionEncodeFn.apply(self.engine, tuple(g[0] for g in groups), self.lora_arena, *[g[1] for g in groups])
+            feats = self._vision_apply(tuple(g[0] for g in groups), [g[1] for g in groups])
         start = 0
         for m, idx, mask in order:
             null = self._ref[f'null_tokens.{m}']

@@ -167,11 +167,12 @@ def test_running_stats_and_state_dict_roundtrip():
         assert torch.equal(sd[k].cpu(), v), k
 
 
-def test_backbone_grad_request_fails_loudly():
+def test_text_tower_grad_request_fails_loudly():
     z, meta = load_case('tiny_eval')
     cfg, arch, state, batch, tokens = case_inputs(meta)
     model = build_model(meta, state, True)
-    dict(model.named_parameters())['clip_encoder.vision_proj.weight'].requires_grad_(True)
+    # the vision backbone has gradients (test_vision_backbone_gradients_random_cotangent); the text tower has none yet
+    dict(model.named_parameters())['clip_encoder.clip_model.text_model.final_layer_norm.weight'].requires_grad_(True)
     with pytest.raises(NotImplementedError):
         model(images={m: t.cuda() for m, t in batch['images'].items()}, texts=batch['texts'],
               modality_masks={m: t.cuda() for m, t in batch['modality_mask'].items()})
@@ -196,7 +197,7 @@ def test_vision_backward_random_cotangent(flavor, tol):
     from prcv2025reid_amd.engine import VisionEncodeFn
     model.engine.refresh()
     mods = tuple(model.vision_modalities.index(m) for m in imgs)
-    feats = VisionEncodeFn.apply(model.engine, mods, model.lora_arena, *[imgs[m].cuda() for m in imgs])
+    feats = VisionEncodeFn.apply(model.engine, mods, model.lora_arena, len(imgs), *[imgs[m].cuda() for m in imgs])
     Rcat = torch.cat([R[m] for m in imgs]).cuda()
     ref_feats = torch.cat([O.encode_vision(imgs[m], m, {k: v.detach() for k, v in state.items()}, arch) for m in imgs])
     print('  feats rel-L2', l2rel(feats.detach().cpu(), ref_feats))
@@ -246,3 +247,47 @@ def test_f16_eval_within_1e3():
     z, meta, model, batch, out = run_case('full_eval_r8', 'f16')
     d = check_forward(z, out, F16_EMB_TOL)
     print(f'  [f16] eval embedding max|delta|={d:.2e}')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# freeze_backbone=False: gradients of the vision backbone itself (weights, biases, LayerNorm affine pairs, position /
+# class embeddings, patch convolutions) against autograd through the oracle, random cotangent (well conditioned).
+@pytest.mark.parametrize('flavor,tol', [('bf16', 4e-2), ('f16', 6e-3)])
+def test_vision_backbone_gradients_random_cotangent(flavor, tol):
+    from oracle import reid_oracle as O
+    z, meta = load_case('tiny_train_all')
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    model = build_model(meta, state, True, flavor)
+    for k, p in model.named_parameters():                   # everything of the vision side trains
+        p.requires_grad_(not k.startswith('clip_encoder.clip_model.') and k != 'clip_encoder.text_proj.weight')
+    g = torch.Generator().manual_seed(11)
+    imgs = {m: torch.randn(2, 3, 224, 224, generator=g) for m in ('vis', 'nir', 'sk', 'cp')}
+    R = {m: torch.randn(2, 512, generator=g) for m in imgs}
+    keys = model.engine.vision_dense_keys()
+    st = {k: (v.clone().requires_grad_(True) if (k in keys or '.loras.' in k) else v) for k, v in state.items()}
+    loss = sum((O.encode_vision(imgs[m], m, st, arch) * R[m]).sum() for m in imgs)
+    loss.backward()
+    model.engine.refresh()
+    feats = model._vision_apply(tuple(model.vision_modalities.index(m) for m in imgs), [imgs[m].cuda() for m in imgs])
+    (feats * torch.cat([R[m] for m in imgs]).cuda()).sum().backward()
+    P = dict(model.named_parameters())
+    worst, n = 0.0, 0
+    for k in keys:
+        ref = st[k].grad
+        assert ref is not None, k
+        got = P[k].grad
+        assert got is not None, k
+        if float(ref.abs().max()) < 1e-10:
+            assert float(got.abs().max()) < 1e-6, k
+            continue
+        if k.endswith('k_proj.shared_linear.bias'):
+            # softmax is invariant to a shift of all keys: this gradient is mathematically zero (the reference holds fp32
+            # round-off there); ours must be small next to the query-bias gradient of the same layer
+            qb = P[k.replace('k_proj', 'q_proj')].grad
+            assert float(got.abs().max()) < 2e-2 * float(qb.abs().max()), k
+            continue
+        e = l2rel(got.detach().cpu(), ref)
+        worst = max(worst, e); n += 1
+        assert e < tol, (k, e)
+    assert n >= 30
+    print(f'  [{flavor}] {n} backbone tensors, worst grad rel-L2 = {worst:.3e}')

@@ -87,7 +87,7 @@ def test_drop_path_forward_backward_vs_oracle(flavor, tol):
     _lib.set_flavor(flavor)
     model.engine.refresh()
     model.engine.pending_drop_scales = [(None if a is None else a.cuda(), None if b is None else b.cuda()) for a, b in scales]
-    fh = VisionEncodeFn.apply(model.engine, (model.vision_modalities.index('nir'),), model.lora_arena, imgs.cuda())
+    fh = VisionEncodeFn.apply(model.engine, (model.vision_modalities.index('nir'),), model.lora_arena, 1, imgs.cuda())
     fh.backward(cot.cuda())
     assert float((fh.detach().cpu() - fo.detach()).norm() / fo.detach().norm()) < tol
     num = den = 0.0
