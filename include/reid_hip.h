@@ -161,6 +161,10 @@ int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table,
 /* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */
 int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd,
                          int32_t rows, int32_t cols, void* stream);
+/* out[index[r], :] += src[r, :] (f32; rows with an index outside [0, out_rows) are skipped): gradient of an embedding
+ * lookup (HF CLIPTextEmbeddings.token_embedding) when the text tower trains. */
+int reid_scatter_add_rows_f32(const float* src, int32_t lds, const int32_t* index, float* out, int32_t ldo,
+                              int32_t rows, int32_t cols, int32_t out_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BN-neck (BNNeck.forward, models/model.py:208-224): BatchNorm1d(D) -> 8*L2-normalise.

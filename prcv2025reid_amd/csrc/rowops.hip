@@ -319,6 +319,28 @@ extern "C" int reid_cls_rows(const float* cls, const float* pos0, float* x, int3
     return REID_OK;
 }
 
+namespace {
+// out[index[r], :] += src[r, :]  (adjoint of the row gather; one wave per source row, fp32 atomics)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int lds_, const int32_t* __restrict__ index,
+                                                               float* __restrict__ out, int ldo, int rows, int cols, int out_rows) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int t = index[r];
+    if (t < 0 || t >= out_rows) return;
+    for (int c = lane; c < cols; c += 64) atomicAdd(out + (size_t)t * ldo + c, src[(size_t)r * lds_ + c]);
+}
+}  // namespace
+
+extern "C" int reid_scatter_add_rows_f32(const float* src, int32_t lds_, const int32_t* index, float* out, int32_t ldo,
+                                         int32_t rows, int32_t cols, int32_t out_rows, void* stream) {
+    REID_CHECK_ARG(src && index && out && rows > 0 && cols > 0 && out_rows > 0, "reid_scatter_add_rows_f32: bad args");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, lds_, index, out, ldo,
+                       rows, cols, out_rows);
+    REID_CHECK_LAUNCH("reid_scatter_add_rows_f32");
+    return REID_OK;
+}
+
 extern "C" int reid_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
     REID_CHECK_ARG(src && dst && n > 0, "reid_cast_f32_bf16: bad args");
     REID_CHECK_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "reid_cast_f32_bf16: pointers must be 16-byte aligned");

@@ -127,7 +127,8 @@ class Engine:
         self._rng = torch.Generator(device=device)
         self._rng.manual_seed(777)
         self.pending_drop_scales = None
-        self.text_backward_ready = False
+        self.text_backward_ready = True
+        self._text_packed = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.W = {}
 
@@ -179,7 +180,14 @@ class Engine:
             W[('t', l, 'out')] = self._bf(P[lp + 'self_attn.out_proj.weight'])
             W[('t', l, 'fc1')] = self._bf(P[lp + 'mlp.fc1.weight'])
             W[('t', l, 'fc2')] = self._bf(P[lp + 'mlp.fc2.weight'])
+            if self.text_trains():                          # transposed packs for the dX products of the text backward
+                W[('t', l, 'qkvT')] = self._bft(wq)
+                W[('t', l, 'outT')] = self._bft(P[lp + 'self_attn.out_proj.weight'])
+                W[('t', l, 'fc1T')] = self._bft(P[lp + 'mlp.fc1.weight'])
+                W[('t', l, 'fc2T')] = self._bft(P[lp + 'mlp.fc2.weight'])
         W['tproj'] = self._bf(P[ce + 'text_proj.weight'])
+        if self.text_trains():
+            W['tprojT'] = self._bft(P[ce + 'text_proj.weight'])
         self.W = W
 
     def pack_lora(self):
@@ -190,8 +198,9 @@ class Engine:
 
     def refresh(self):
         dv = sum(p._version for k, p in self.P.items() if k.startswith('clip_encoder.') and p is not self.lora_arena)
-        if dv != self._dense_ver:
-            self.pack_dense(); self._dense_ver = dv
+        tt = self.text_trains()
+        if dv != self._dense_ver or tt != self._text_packed:
+            self.pack_dense(); self._dense_ver = dv; self._text_packed = tt
         lv = self.lora_arena._version
         if lv != self._lora_ver:
             self.pack_lora(); self._lora_ver = lv
@@ -463,7 +472,17 @@ class Engine:
         return (grad, dense) if want_dense else grad
 
     # ------------------------------------------------------------------------------- text forward
-    def text_forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    def text_keys(self) -> List[str]:
+        """Reference keys of the text tower + its projection, in a fixed order (inputs / gradient outputs of TextEncodeFn)."""
+        tp = 'clip_encoder.clip_model.text_model.'
+        return [k for k in self.P if k.startswith(tp)] + ['clip_encoder.text_proj.weight']
+
+    def text_trains(self) -> bool:
+        return any(self.P[k].requires_grad for k in self.text_keys())
+
+    def text_forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], save: bool = False):
+        """HF CLIP text tower + text_proj (clip_backbone.py:288-313).  ``save``: also return the activations the backward
+        pass needs (``(features, state)``); the default returns the features only."""
         a, P, W = self.arch, self.P, self.W
         dev = self.dev
         tp = 'clip_encoder.clip_model.text_model.'
@@ -478,25 +497,141 @@ class Engine:
         if attention_mask is not None:
             km = attention_mask.to(dev).to(torch.uint8).contiguous()
         M = B * T
-        h = torch.empty(M, td, **b16); qkv = torch.empty(M, 3 * td, **b16); o = torch.empty(M, td, **b16)
-        g = torch.empty(M, tff, **b16); xm = torch.empty(M, td, **f32); xn = torch.empty(M, td, **f32)
+        layers = []
+        if not save:
+            h = torch.empty(M, td, **b16); qkv = torch.empty(M, 3 * td, **b16); o = torch.empty(M, td, **b16)
+            g = torch.empty(M, tff, **b16); xm = torch.empty(M, td, **f32); xn = torch.empty(M, td, **f32)
         for l in range(a['text_layers']):
             lp = f'{tp}encoder.layers.{l}.'
-            ops.layernorm_fwd(x, P[lp + 'layer_norm1.weight'], P[lp + 'layer_norm1.bias'], y_bf16=h)
+            if save:
+                h = torch.empty(M, td, **b16); qkv = torch.empty(M, 3 * td, **b16); o = torch.empty(M, td, **b16)
+                g = torch.empty(M, tff, **b16); xm = torch.empty(M, td, **f32); xn = torch.empty(M, td, **f32)
+                h2 = torch.empty(M, td, **b16); u = torch.empty(M, tff, **b16); lse = torch.empty(B, heads, T, **f32)
+                m1 = torch.empty(M, **f32); r1 = torch.empty(M, **f32); m2 = torch.empty(M, **f32); r2 = torch.empty(M, **f32)
+            else:
+                h2, u, lse, m1, r1, m2, r2 = h, None, None, None, None, None, None
+            ops.layernorm_fwd(x, P[lp + 'layer_norm1.weight'], P[lp + 'layer_norm1.bias'], y_bf16=h, mean=m1, rstd=r1)
             ops.gemm(h, W[('t', l, 'qkv')], qkv, bias=W[('t', l, 'bqkv')])
-            ops.attn_fwd(qkv, o, None, B, T, heads, causal=True, key_mask=km)
+            ops.attn_fwd(qkv, o, lse, B, T, heads, causal=True, key_mask=km)
             ops.gemm(o, W[('t', l, 'out')], xm, bias=P[lp + 'self_attn.out_proj.bias'], R=x)
-            ops.layernorm_fwd(xm, P[lp + 'layer_norm2.weight'], P[lp + 'layer_norm2.bias'], y_bf16=h)
-            ops.gemm(h, W[('t', l, 'fc1')], g, bias=P[lp + 'mlp.fc1.bias'], act='quick_gelu')
+            ops.layernorm_fwd(xm, P[lp + 'layer_norm2.weight'], P[lp + 'layer_norm2.bias'], y_bf16=h2, mean=m2, rstd=r2)
+            ops.gemm(h2, W[('t', l, 'fc1')], g, bias=P[lp + 'mlp.fc1.bias'], act='quick_gelu', C2=u)
             ops.gemm(g, W[('t', l, 'fc2')], xn, bias=P[lp + 'mlp.fc2.bias'], R=xm)
-            x, xn = xn, x
+            if save:
+                layers.append(dict(x=x, h=h, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, xm=xm, h2=h2, m2=m2, r2=r2, u=u, g=g))
+                x = xn
+            else:
+                x, xn = xn, x
         eos = (ids == a['text_eos_id']).int().argmax(dim=-1)                  # first EOS (HF pooling rule)
         idx = (torch.arange(B, device=dev) * T + eos).to(torch.int32)
         pooled = torch.empty(B, td, **b16)
-        ops.layernorm_fwd(x, P[tp + 'final_layer_norm.weight'], P[tp + 'final_layer_norm.bias'], y_bf16=pooled, row_index=idx)
+        mf = torch.empty(B, **f32) if save else None; rf = torch.empty(B, **f32) if save else None
+        ops.layernorm_fwd(x, P[tp + 'final_layer_norm.weight'], P[tp + 'final_layer_norm.bias'], y_bf16=pooled, mean=mf, rstd=rf,
+                          row_index=idx)
         feats = torch.empty(B, a['fusion_dim'], **f32)
         ops.gemm(pooled, W['tproj'], feats)
+        if not save:
+            return feats
+        return feats, dict(layers=layers, x_final=x, idx=idx, mf=mf, rf=rf, pooled=pooled, ids=ids, km=km, B=B, T=T)
+
+    def text_backward(self, st, dfeat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """dfeat f32 [B, D] -> {reference key: fp32 gradient} for every tensor of ``text_keys()`` (freeze_backbone=False /
+        freeze_text_backbone=False).  Same scheme as the vision backward without LoRA: dX through transposed 16-bit packs,
+        dW = dY^T X on the reduce-over-rows GEMM, biases as column sums, LayerNorm pairs from the LN backward kernel, causal
+        attention backward, embedding tables by scatter-add / batch sum."""
+        a, P, W = self.arch, self.P, self.W
+        dev = self.dev
+        tp = 'clip_encoder.clip_model.text_model.'
+        B, T = st['B'], st['T']
+        M = B * T
+        td, tff, heads = a['text_hidden_dim'], a['text_mlp_dim'], a['text_heads']
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
+        G: Dict[str, torch.Tensor] = {}
+        scale_t = None
+        if self.loss_scaling:
+            amax = dfeat.abs().amax().clamp_min(1e-30)
+            scale_t = torch.exp2(torch.floor(torch.log2(512.0 / amax))).clamp(2.0 ** -20, 2.0 ** 40)
+            dfeat = dfeat * scale_t
+        ones8 = torch.ones(M, 8, **b16)
+
+        def wgrad(dY, X):
+            out = torch.empty(dY.shape[1], X.shape[1], **f32)
+            ops.gemm_tn(dY, X, out)
+            return out
+
+        def colsum(dY):
+            out = torch.empty(dY.shape[1], 8, **f32)
+            ops.gemm_tn(dY, ones8[:dY.shape[0]], out)
+            return out[:, 0].contiguous()
+
+        def ln_pair(key):
+            G[key + '.weight'] = torch.zeros(td, **f32); G[key + '.bias'] = torch.zeros(td, **f32)
+            return G[key + '.weight'], G[key + '.bias']
+
+        dfb = ops.to_bf16(dfeat)
+        G['clip_encoder.text_proj.weight'] = wgrad(dfb, st['pooled'])
+        dpool = torch.empty(B, td, **b16)
+        ops.gemm(dfb, W['tprojT'], dpool)
+        dx = torch.zeros(M, td, **f32); dxb = torch.zeros(M, td, **b16)
+        dg_, db_ = ln_pair(tp + 'final_layer_norm')
+        ops.layernorm_bwd(dpool, st['x_final'], P[tp + 'final_layer_norm.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
+                          row_index=st['idx'], dgamma=dg_, dbeta=db_)
+        du = torch.empty(M, tff, **b16); dh = torch.empty(M, td, **b16); do = torch.empty(M, td, **b16)
+        dqkv = torch.empty(M, 3 * td, **b16); delta = torch.empty(B, heads, T, **f32)
+        dxm = torch.empty(M, td, **f32); dxmb = torch.empty(M, td, **b16)
+        for l in reversed(range(a['text_layers'])):
+            s = st['layers'][l]
+            lp = f'{tp}encoder.layers.{l}.'
+            ops.gemm(dxb, W[('t', l, 'fc2T')], du, act='dquick_gelu', aux=s['u'])
+            G[lp + 'mlp.fc2.weight'] = wgrad(dxb, s['g']); G[lp + 'mlp.fc2.bias'] = colsum(dxb)
+            ops.gemm(du, W[('t', l, 'fc1T')], dh)
+            G[lp + 'mlp.fc1.weight'] = wgrad(du, s['h2']); G[lp + 'mlp.fc1.bias'] = colsum(du)
+            dg_, db_ = ln_pair(lp + 'layer_norm2')
+            ops.layernorm_bwd(dh, s['xm'], P[lp + 'layer_norm2.weight'], s['m2'], s['r2'], dxm, dx_bf16=dxmb, dres=dx,
+                              dgamma=dg_, dbeta=db_)
+            ops.gemm(dxmb, W[('t', l, 'outT')], do)
+            G[lp + 'self_attn.out_proj.weight'] = wgrad(dxmb, s['o']); G[lp + 'self_attn.out_proj.bias'] = colsum(dxmb)
+            ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, B, T, heads, causal=True, key_mask=st['km'])
+            ops.gemm(dqkv, W[('t', l, 'qkvT')], dh)
+            gw = wgrad(dqkv, s['h']); gb = colsum(dqkv)
+            for gi, nm in enumerate('qkv'):
+                G[lp + f'self_attn.{nm}_proj.weight'] = gw[gi * td:(gi + 1) * td]
+                G[lp + f'self_attn.{nm}_proj.bias'] = gb[gi * td:(gi + 1) * td]
+            dg_, db_ = ln_pair(lp + 'layer_norm1')
+            ops.layernorm_bwd(dh, s['x'], P[lp + 'layer_norm1.weight'], s['m1'], s['r1'], dx, dx_bf16=dxb, dres=dxm,
+                              dgamma=dg_, dbeta=db_)
+        # embeddings: x0[b, t] = tok[ids[b, t]] + pos[t]
+        tok = P[tp + 'embeddings.token_embedding.weight']; posw = P[tp + 'embeddings.position_embedding.weight']
+        dtok = torch.zeros(tok.shape, **f32)
+        ops.scatter_add_rows(dx, st['ids'].reshape(-1).to(torch.int32).contiguous(), dtok)
+        dpos = torch.zeros(posw.shape, **f32)
+        dsum = torch.empty(1, T * td, **f32)
+        ops.sgemm(torch.ones(1, B, **f32), dx.view(B, T * td), dsum)
+        dpos[:T] = dsum.view(T, td)
+        G[tp + 'embeddings.token_embedding.weight'] = dtok
+        G[tp + 'embeddings.position_embedding.weight'] = dpos
+        if scale_t is not None:
+            for k in G:
+                G[k] = G[k] * (1.0 / scale_t)
+        return G
+
+
+class TextEncodeFn(torch.autograd.Function):
+    """Autograd boundary of the text executor when the text tower trains: (tokens, text tensors) -> [B, D] features."""
+
+    @staticmethod
+    def forward(ctx, engine: Engine, input_ids, attention_mask, *params):
+        feats, st = engine.text_forward(input_ids, attention_mask, save=True)
+        ctx.engine, ctx.st, ctx.n = engine, st, len(params)
         return feats
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        _lib.set_flavor(ctx.engine.flavor)
+        G = ctx.engine.text_backward(ctx.st, dfeat.contiguous().float())
+        ctx.st = None
+        keys = ctx.engine.text_keys()
+        return (None, None, None) + tuple(G.get(k) if ctx.needs_input_grad[3 + i] else None for i, k in enumerate(keys))
 
 
 class VisionEncodeFn(torch.autograd.Function):

@@ -20,9 +20,9 @@ Deliberate differences (documented in DESIGN.md):
     with torch's: the reference draws per modality pass, here the modalities run packed); modality dropout masks the dropped
     modality's fusion slot instead of removing it from the list (same function, static shapes); the reference's train/eval
     asymmetry (SDM module only in train mode, models/model.py:395-399) is kept;
-  * gradients are implemented for what the reference trains by default (train.py:1418-1425: LoRA,
-    bn_neck, null_tokens) plus the torch-side head modules; asking for gradients of frozen-by-default
-    backbone tensors raises NotImplementedError instead of silently returning none.
+  * gradients exist for EVERY parameter (freeze_backbone=False works): the LoRA / bn_neck / null-token default set on the
+    fast path, and -- only when such a tensor has requires_grad -- the vision backbone (VisionEncodeFn's extra inputs) and the
+    text tower (TextEncodeFn); the frozen default carries none of that state or work.
 """
 import logging
 from collections import OrderedDict
@@ -33,7 +33,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .config import arch_of
-from .engine import Engine, LoraLayout, VisionEncodeFn
+from .engine import TextEncodeFn, Engine, LoraLayout, VisionEncodeFn
 from .head import (MulFn, ActFn, AddFn, BNNeckFn, CrossEntropyLSFn, LayerNormF32Fn, LinearF32Fn, LinearNdF32Fn, MaskedMeanFn,
                    NanToNumFn, SDMFn, SmallAttnFn)
 from .tokenizer import load_tokenizer
@@ -243,6 +243,13 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             if p.requires_grad and k.startswith('clip_encoder.clip_model.text_model.') and not self.engine.text_backward_ready:
                 raise NotImplementedError(f'gradient of {k} requested: the text tower has no backward pass in this build')
 
+    def _text_apply(self, ids, am):
+        """Text tower + projection; through TextEncodeFn (activations saved, backward available) only when one of its tensors
+        trains (freeze_backbone=False and freeze_text_backbone=False) -- the reference default runs it forward-only."""
+        if torch.is_grad_enabled() and self.engine.text_trains():
+            return TextEncodeFn.apply(self.engine, ids, am, *[self._ref[k] for k in self.engine.text_keys()])
+        return self.engine.text_forward(ids, am)
+
     def _vision_apply(self, mods, images):
         """VisionEncodeFn with the backbone tensors as extra autograd inputs only when one of them trains
         (freeze_backbone=False); the reference default (train.py:1418-1425) passes none."""
@@ -272,7 +279,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         ids, am = self._tokens(texts)
-        return self.engine.text_forward(ids, am)
+        return self._text_apply(ids, am)
 
     def seed_stochastic(self, seed: int, rank: int = 0):
         """Reseed the regularisers' generators (head masks identical on every rank, DropPath per rank)."""
@@ -463,7 +470,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         n_text = 0 if texts is None else (texts['input_ids'].shape[0] if isinstance(texts, dict) else len(texts))
         if texts is not None and n_text > 0:
             ids, am = self._tokens(texts)
-            tf = self.engine.text_forward(ids, am)
+            tf = self._text_apply(ids, am)
             tmd = plan['text'][2]
             if plan['text'][0] != 'all':
                 tf = torch.where(tmd.bool().view(B, 1), tf, self._ref['null_tokens.text'].expand(B, -1))

@@ -288,3 +288,9 @@ def rank_metrics(scores, g_pid, g_img, q_pid, q_slot, q_excl, csr_off, csr_idx, 
     check(lib().reid_rank_metrics(ptr(scores), C.c_int64(scores.stride(0)), ptr(g_pid), ptr(g_img), ptr(q_pid), ptr(q_slot),
                                   ptr(q_excl), ptr(csr_off), ptr(csr_idx), scores.shape[0], Ng, max_pos, ptr(ap), ptr(rank1), ptr(npos),
                                   stream_ptr()))
+
+
+def scatter_add_rows(src, index, out):
+    """out[index[r]] += src[r] (f32 rows; int32 index)."""
+    check(lib().reid_scatter_add_rows_f32(ptr(src), src.stride(0), ptr(index), ptr(out), out.stride(0), src.shape[0], src.shape[1],
+                                          out.shape[0], stream_ptr()))

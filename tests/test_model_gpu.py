@@ -110,6 +110,8 @@ def check_train(z, meta, model, batch, out):
             assert g is None or float(g.abs().max()) < 1e-6, key
             continue
         assert g is not None, key
+        if 'k_proj' in key and key.endswith('bias'):   # mathematically zero (softmax shift invariance): fp32 round-off in the reference
+            continue
         e = l2rel(g.detach().cpu(), ref)
         worst = max(worst, e)
         errs.append((key, e))
@@ -167,15 +169,60 @@ def test_running_stats_and_state_dict_roundtrip():
         assert torch.equal(sd[k].cpu(), v), k
 
 
-def test_text_tower_grad_request_fails_loudly():
-    z, meta = load_case('tiny_eval')
+@pytest.mark.parametrize('flavor,tol', [('bf16', 4e-2), ('f16', 6e-3)])
+def test_text_tower_gradients_random_cotangent(flavor, tol):
+    """freeze_backbone=False, text side: every tensor of the text tower + text_proj against autograd through the oracle."""
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd import _lib
+    z, meta = load_case('tiny_train_all')
     cfg, arch, state, batch, tokens = case_inputs(meta)
-    model = build_model(meta, state, True)
-    # the vision backbone has gradients (test_vision_backbone_gradients_random_cotangent); the text tower has none yet
-    dict(model.named_parameters())['clip_encoder.clip_model.text_model.final_layer_norm.weight'].requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        model(images={m: t.cuda() for m, t in batch['images'].items()}, texts=batch['texts'],
-              modality_masks={m: t.cuda() for m, t in batch['modality_mask'].items()})
+    model = build_model(meta, state, True, flavor)
+    keys = model.engine.text_keys()
+    for k, p in model.named_parameters():
+        p.requires_grad_(k in keys)
+    ids = tokens['input_ids']; am = tokens['attention_mask']
+    g = torch.Generator().manual_seed(5)
+    R = torch.randn(ids.shape[0], 512, generator=g)
+    st = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in state.items()}
+    (O.encode_text(ids, am, st, arch) * R).sum().backward()
+    _lib.set_flavor(flavor)
+    model.engine.refresh()
+    f = model._text_apply(ids.cuda(), am.cuda())
+    (f * R.cuda()).sum().backward()
+    P = dict(model.named_parameters())
+    worst, n = 0.0, 0
+    for k in keys:
+        ref, got = st[k].grad, P[k].grad
+        assert ref is not None and got is not None, k
+        if float(ref.abs().max()) < 1e-10:
+            assert float(got.abs().max()) < 1e-6, k
+            continue
+        if k.endswith('k_proj.bias'):                       # mathematically zero (softmax shift invariance)
+            assert float(got.abs().max()) < 2e-2 * float(P[k.replace('k_proj', 'q_proj')].grad.abs().max()), k
+            continue
+        e = l2rel(got.detach().cpu(), ref)
+        worst = max(worst, e); n += 1
+        assert e < tol, (k, e)
+    assert n >= 25
+    print(f'  [{flavor}] {n} text tensors, worst grad rel-L2 = {worst:.3e}')
+
+
+def test_everything_trains_vs_reference_fixture():
+    """tiny_train_all: the reference with every parameter trainable (freeze_backbone=False) -- losses and the recorded gradients.
+    f16 operands: per-tensor gradients of the FULL loss are too badly conditioned for bf16 on this fixture (see GRAD_TOL above;
+    the backward kernels themselves are gated by the random-cotangent tests in both flavors)."""
+    z, meta = load_case('tiny_train_all')
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    check_fingerprint(z, state)
+    model = build_model(meta, state, True, 'f16')
+    for k, p in model.named_parameters():
+        p.requires_grad_(True)
+    images = {m: t.cuda() for m, t in batch['images'].items()}
+    masks = {m: t.cuda() for m, t in batch['modality_mask'].items()}
+    out = model(images=images, texts=batch['texts'], modality_masks=masks)
+    d = check_forward(z, out, EMB_TOL_TRAIN)
+    w = check_train(z, meta, model, batch, out)
+    print(f'tiny_train_all: embedding max|delta|={d:.2e} worst grad rel-L2={w:.2e}')
 
 
 @pytest.mark.parametrize('flavor,tol', [('bf16', 3e-2), ('f16', 5e-3)])
