@@ -291,8 +291,8 @@ def main():
         if ln_prof:
             nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
             gbs = nb / (ms * 1e-3) / 1e9
-            res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
+            res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true, false>') or pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
                                    'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
         if world == 1 and not args.no_retrieval:
             del opt
