@@ -109,3 +109,49 @@ class DataParallel:
             for p in small:
                 n = p.numel()
                 p.grad.copy_(flat[o:o + n].view_as(p.grad)); o += n
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Sharded gallery retrieval: gallery rows split over ranks, queries replicated
+def merge_topk(idx_parts: torch.Tensor, score_parts: torch.Tensor, k: int):
+    """Merge W per-shard top-k lists into the global top-k under the ranking rule of the single-GPU path
+    (score descending, GLOBAL gallery index ascending on ties).
+
+    idx_parts int32/int64 [W, Nq, k] (global indices, -1 = no entry), score_parts f32 [W, Nq, k] -> (idx [Nq, k], score [Nq, k]).
+    Exact: every member of the global top-k is in the top-k of the shard that holds it.
+    Pure index bookkeeping on k*W candidates per query (the heavy part, scoring the shard, is the HIP kernel)."""
+    W, Nq, kk = idx_parts.shape
+    idx = idx_parts.permute(1, 0, 2).reshape(Nq, W * kk).long()
+    sc = score_parts.permute(1, 0, 2).reshape(Nq, W * kk).float()
+    sc = torch.where(idx < 0, torch.full_like(sc, float('-inf')), sc)
+    # two stable sorts = lexicographic (score desc, index asc)
+    o1 = torch.argsort(torch.where(idx < 0, torch.full_like(idx, 1 << 62), idx), dim=1, stable=True)
+    idx1, sc1 = idx.gather(1, o1), sc.gather(1, o1)
+    o2 = torch.argsort(sc1, dim=1, descending=True, stable=True)[:, :k]
+    return idx1.gather(1, o2), sc1.gather(1, o2)
+
+
+class ShardedGalleryIndex:
+    """Rank r holds gallery rows [r*Ng/W, (r+1)*Ng/W); ``topk`` runs the local fused cosine top-k (retrieval.GalleryIndex),
+    all-gathers the k*W candidates (k*8 bytes per query per rank) and merges them -- the global fp32 ranking, exactly."""
+
+    def __init__(self, local_gallery: torch.Tensor, shard_offset: int, group=None, normalized: bool = False, img_ids=None):
+        from .retrieval import GalleryIndex
+        self.local = GalleryIndex(local_gallery, normalized=normalized, img_ids=img_ids)
+        self.offset = int(shard_offset)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False, query_img_ids=None):
+        kk = min(k, self.local.Gf.shape[0])
+        idx, sc = self.local.topk(queries, k=kk, normalized=normalized, query_img_ids=query_img_ids)
+        idx = torch.where(idx >= 0, idx.long() + self.offset, idx.long())
+        if kk < k:                                            # a shard smaller than k: pad with empty entries
+            pad = k - kk
+            idx = torch.cat([idx, torch.full((idx.shape[0], pad), -1, dtype=idx.dtype, device=idx.device)], 1)
+            sc = torch.cat([sc, torch.full((sc.shape[0], pad), float('-inf'), device=sc.device)], 1)
+        if self.world == 1:
+            return merge_topk(idx.unsqueeze(0), sc.unsqueeze(0), k)
+        gi = gather_no_grad(idx.unsqueeze(0).contiguous(), self.group)
+        gs = gather_no_grad(sc.unsqueeze(0).contiguous(), self.group)
+        return merge_topk(gi, gs, k)

@@ -446,3 +446,19 @@ def test_cosine_topk_overflow_fallback_is_exact(ops):
         for r in range(k):
             a, b = int(ref[qi, r]), int(idx[qi, r])
             assert a == b or abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
+
+
+def test_sharded_gallery_single_process(ops):
+    """ShardedGalleryIndex with one rank (no process group) == GalleryIndex on the whole gallery; offsets applied."""
+    from prcv2025reid_amd.parallel import ShardedGalleryIndex, merge_topk
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    g = torch.Generator(device='cuda').manual_seed(4)
+    Q = torch.randn(33, 512, device='cuda', generator=g); G = torch.randn(3000, 512, device='cuda', generator=g)
+    want_i, want_s = GalleryIndex(G).topk(Q, k=10)
+    parts_i, parts_s = [], []
+    for a, b in ((0, 1000), (1000, 1900), (1900, 3000)):
+        sh = ShardedGalleryIndex(G[a:b], a)
+        i, s = sh.topk(Q, k=10)
+        parts_i.append(i); parts_s.append(s)
+    gi, gs = merge_topk(torch.stack(parts_i), torch.stack(parts_s), 10)
+    assert torch.equal(gi, want_i.long()) and torch.allclose(gs, want_s)

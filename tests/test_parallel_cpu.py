@@ -86,3 +86,59 @@ def test_global_head_on_gathered_features_equals_single_process(tmp_path):
         assert abs(float(o['loss']) - float(ref)) < 1e-6                      # same global loss on every rank
         for m in mods:
             assert float((o['grads'][m] - Wp[m].grad).abs().max()) < 1e-5 * max(1.0, float(Wp[m].grad.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_merge_topk_equals_global_ranking():
+    """Per-shard top-k lists (made here with the oracle's ranking rule) merge into the global top-k, ties included."""
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd.parallel import merge_topk
+    g = torch.Generator().manual_seed(3)
+    Nq, Ng, D, k, W = 17, 403, 32, 10, 4
+    Q = O.l2n(torch.randn(Nq, D, generator=g)); G = O.l2n(torch.randn(Ng, D, generator=g))
+    G[100] = G[7]; G[301] = G[7]; G[302] = G[7]                       # exact ties across shards
+    want_idx, want_sc = O.topk_ranklist(Q, G, k)
+    bounds = [0, 101, 202, 303, Ng]
+    parts_i, parts_s = [], []
+    for w in range(W):
+        a, b = bounds[w], bounds[w + 1]
+        li, ls = O.topk_ranklist(Q, G[a:b], k)
+        parts_i.append(li + a); parts_s.append(ls)
+    gi, gs = merge_topk(torch.stack(parts_i), torch.stack(parts_s), k)
+    assert torch.equal(gi, want_idx) and torch.allclose(gs, want_sc, atol=0, rtol=0)
+    # shards shorter than k are padded with -1 / -inf
+    li, ls = O.topk_ranklist(Q, G[:4], 4)
+    pad_i = torch.cat([li, torch.full((Nq, k - 4), -1)], 1); pad_s = torch.cat([ls, torch.full((Nq, k - 4), float('-inf'))], 1)
+    li2, ls2 = O.topk_ranklist(Q, G[4:], k)
+    gi, gs = merge_topk(torch.stack([pad_i, li2 + 4]), torch.stack([pad_s, ls2]), k)
+    assert torch.equal(gi, want_idx)
+
+
+def _shard_worker(rank, world, port):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd import parallel as PAR
+    g = torch.Generator().manual_seed(9)
+    Nq, Ng, D, k = 11, 120, 16, 5
+    Q = O.l2n(torch.randn(Nq, D, generator=g)); G = O.l2n(torch.randn(Ng, D, generator=g))
+    a, b = rank * Ng // world, (rank + 1) * Ng // world
+
+    class LocalIndex:                                       # the HIP GalleryIndex needs a GPU: the oracle ranks this rank's shard
+        def __init__(self, Gl):
+            self.Gf = Gl
+        def topk(self, q, k=10, normalized=False, query_img_ids=None):
+            i, s = O.topk_ranklist(q, self.Gf, k)
+            return i.to(torch.int32), s
+    idx = PAR.ShardedGalleryIndex.__new__(PAR.ShardedGalleryIndex)
+    idx.local, idx.offset, idx.group, idx.world = LocalIndex(G[a:b]), a, None, world
+    gi, gs = idx.topk(Q, k=k, normalized=True)
+    want_i, want_s = O.topk_ranklist(Q, G, k)
+    assert torch.equal(gi, want_i) and torch.equal(gs, want_s), rank
+    dist.destroy_process_group()
+
+
+def test_sharded_gallery_gloo():
+    port = 29641
+    mp.spawn(_shard_worker, args=(2, port), nprocs=2, join=True)
