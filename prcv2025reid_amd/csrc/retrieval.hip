@@ -31,7 +31,77 @@ struct TopkParams {
     float* dense; int ld_dense;    // phase A: dense scores [Nq, g_end-g_begin]
     int32_t* cand_idx; float* cand_score; int32_t* cand_cnt; int cap;   // phase B
     int tiles_m, tiles_n;
+    int dbg;                       // timing experiments (REID_TOPK_DBG): 1 = skip the compare epilogue
 };
+
+// Compare epilogue shared by the filter kernels.  A lane owns, per 16-row group i, ONE query row and 16 of its scores
+// (4 sub-tiles x 4 columns).  Survivors (0.1 % of the scores, but ~300 per tile) are first collected as a bit mask per
+// (lane, i); the per-(row, lane) counts then go through a 1 KiB wave-private LDS slice so that lane L of the wave owns ROW L
+// of the wave's 64-row group: ONE atomicAdd wave-instruction per 64 rows reserves the slots of every row at once (64 lanes,
+// 64 different counters), the bases come back through the same LDS slice, and only then are the survivors written.
+// History (10k x 200k, 128x256 tiles): one dependent global atomic per survivor inside the compare loop 1.7 ms of the 3.4 ms
+// filter pass; one atomic instruction per (i) 1.0 ms; this form: see DESIGN.md.  Global atomics cost ~50 ns of CU
+// throughput per wave-instruction whatever the number of active lanes (MI355X_MICROARCH.md), so the lever is the
+// instruction count, not the survivor count.
+template <int TM, int TN>
+__device__ __forceinline__ void filter_epilogue(const TopkParams& p, f32x4 (&acc)[TN][TM], const float (&th)[TM], int m_base, int n_base,
+                                                int lane, int* wl /* >= 256 ints of wave-private LDS */) {
+    static_assert(TM % 4 == 0 && TN <= 8, "64-row groups; survivor mask of TN*4 <= 32 bits");
+    const int frow = lane & 15, fq = lane >> 4;
+    unsigned msk[TM];
+    int slot0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_base + i * 16 + frow;
+        const bool mok = m < p.Nq;
+        const int eq = p.exq ? p.exq[mok ? m : 0] : -1;
+        unsigned b = 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[j][i][e];
+                if (eq >= 0 && n + e < p.g_end && p.exg[n + e] == eq) { v = -1e9f; acc[j][i][e] = v; }
+                if (mok && v >= th[i] && n + e < p.g_end) b |= 1u << (j * 4 + e);
+            }
+        }
+        msk[i] = b;
+    }
+#pragma unroll
+    for (int h = 0; h < TM / 4; ++h) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) wl[(ii * 16 + frow) * 4 + fq] = __builtin_popcount(msk[4 * h + ii]);
+        __builtin_amdgcn_wave_barrier();
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 c = *(const i32x4*)(wl + lane * 4);       // lane L: the four per-quarter counts of row L of this 64-row group
+        const int tot = c[0] + c[1] + c[2] + c[3];
+        const int base = tot ? atomicAdd(p.cand_cnt + (m_base + h * 64 + lane), tot) : 0;   // (tot > 0 implies the row is < Nq)
+        __builtin_amdgcn_wave_barrier();
+        *(i32x4*)(wl + lane * 4) = i32x4{base, base + c[0], base + c[0] + c[1], base + c[0] + c[1] + c[2]};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) slot0[4 * h + ii] = wl[(ii * 16 + frow) * 4 + fq];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (msk[i] == 0) continue;
+        const int m = m_base + i * 16 + frow;
+        int slot = slot0[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((msk[i] >> (j * 4 + e)) & 1u) {
+                    if (slot < p.cap) {
+                        p.cand_idx[(size_t)m * p.cap + slot] = n_base + j * 16 + fq * 4 + e;
+                        p.cand_score[(size_t)m * p.cap + slot] = acc[j][i][e];
+                    }
+                    ++slot;
+                }
+    }
+}
 
 template <int BM, int BN, int WM, int WN, bool DENSE>
 __global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) {
@@ -50,16 +120,28 @@ __global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) 
     for (int j = 0; j < C::TN; ++j)
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int mrow = lane & 15, ncol4 = (lane >> 4) * 4;
+    float th[C::TM];
+    if (!DENSE) {                                         // requested before the K loop: its L2 latency hides behind the first K-steps
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + mrow;
+            th[i] = p.dbg == 2 ? INFINITY : p.thr[m < p.Nq ? m : 0];
+        }
+    }
     // no low-rank pair: K2 = 0 (non-null dummies keep the staging code free of constant-null pointers)
     mainloop<BM, BN, WM, WN>(p.Q, p.D, p.G, p.D, p.Q, p.D, p.G, p.D, p.Nq, p.g_end, p.D, 0, m0, n0, smem, acc);
-    const int mrow = lane & 15, ncol4 = (lane >> 4) * 4;
+    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+    if (!DENSE) {
+        __syncthreads();                                    // every wave is done reading the operand buffers: reuse them
+        filter_epilogue<C::TM, C::TN>(p, acc, th, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, (int*)(smem + wave * 1024));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + mrow;
         const bool mok = m < p.Nq;
-        const int mc = mok ? m : 0;
-        const float th = DENSE ? -INFINITY : p.thr[mc];
-        const int eq = p.exq ? p.exq[mc] : -1;
+        const int eq = p.exq ? p.exq[mok ? m : 0] : -1;
 #pragma unroll
         for (int j = 0; j < C::TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + ncol4;
@@ -69,26 +151,11 @@ __global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) 
                 for (int e = 0; e < 4; ++e)
                     if (n + e < p.g_end && p.exg[n + e] == eq) v[e] = -1e9f;
             }
-            if (DENSE) {
-                if (mok) {
-                    float* d = p.dense + (size_t)m * p.ld_dense + (n - p.g_begin);
+            if (mok) {
+                float* d = p.dense + (size_t)m * p.ld_dense + (n - p.g_begin);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.g_end) d[e] = v[e];
-                }
-            } else {
-                const bool any = mok && (v[0] >= th || v[1] >= th || v[2] >= th || v[3] >= th);
-                if (any) {
-                    for (int e = 0; e < 4; ++e) {
-                        if (v[e] >= th && n + e < p.g_end) {
-                            const int slot = atomicAdd(p.cand_cnt + m, 1);
-                            if (slot < p.cap) {
-                                p.cand_idx[(size_t)m * p.cap + slot] = n + e;
-                                p.cand_score[(size_t)m * p.cap + slot] = v[e];
-                            }
-                        }
-                    }
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.g_end) d[e] = v[e];
             }
         }
     }
@@ -367,6 +434,7 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     TopkParams p{};
     p.Q = (const bf16_t*)Q_bf16; p.G = (const bf16_t*)G_bf16; p.Nq = Nq; p.Ng = Ng; p.D = D;
     p.exq = exclude_q; p.exg = exclude_g; p.cap = cap;
+    { const char* e = getenv("REID_TOPK_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.tiles_m = (Nq + BM - 1) / BM;
     // phase A: sample = first ns gallery rows, dense scores, k-th best -> thr
     p.g_begin = 0; p.g_end = ns; p.thr = nullptr; p.dense = dense; p.ld_dense = ns;
@@ -385,14 +453,16 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     p.cand_idx = cidx; p.cand_score = cscore; p.cand_cnt = cnt;
     {
         const char* e = getenv("REID_TOPK_TILE");
-        // the filter epilogue is a compare (stores are rare), so unlike the training GEMMs the 256x256 tile wins here:
-        // 10k x 200k x 512: 3.35 ms vs 3.68 ms with 128x128 (REID_TOPK_TILE=0/1/2/3 A/B, r01)
-        const int tile = e ? atoi(e) : ((Nq >= 512 && Ng >= 4096) ? 3 : 0);
+        // Filter-pass anatomy at 10k x 200k x 512 (REID_TOPK_DBG=1/2, r01): K loops 1.1-1.7 ms depending on the tile, compare of
+        // every score against its row threshold 0.7 ms, candidate appends 0.6 ms; 128x128 / 128x256 / 256x128 tiles all end
+        // at 4.0-4.1 ms per top-10 call.  Tried and dropped: a persistent variant with a 3-stage ring across tiles (4.02 ms: the
+        // per-tile latency it removes is not the bottleneck), the 256x256 tile (fastest K loop, but its epilogue spills).
+        const int tile = e ? atoi(e) : 2;
         int rc;
         if (tile == 1) rc = launch_filter<256, 128, 4, 2>(p, s);
-        else if (tile == 2) rc = launch_filter<128, 256, 2, 4>(p, s);
         else if (tile == 3) rc = launch_filter<256, 256, 2, 4>(p, s);
-        else rc = launch_filter<128, 128, 2, 2>(p, s);
+        else if (tile == 0 || Nq < 256 || Ng < 1024) rc = launch_filter<128, 128, 2, 2>(p, s);
+        else rc = launch_filter<128, 256, 2, 4>(p, s);
         if (rc) return rc;
     }
     // phase C
