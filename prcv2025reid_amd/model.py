@@ -479,7 +479,15 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             raise ValueError('at least one modality is required')
         if gather_fn is not None:
             raw, fmask = gather_fn(raw, fmask)
-        sem = OrderedDict((m, self._sdm_module(f) if self.training else f) for m, f in raw.items())
+        if self.training:
+            # the SDM module is shared by all modalities (model.py:395-399): one pass over the stacked [n_mod*B, D] rows instead
+            # of one per modality (same arithmetic per row, 5x fewer of the ~20 tiny launches of its forward + backward)
+            names = list(raw.keys())
+            Bg = raw[names[0]].shape[0]
+            ys = self._sdm_module(torch.cat([raw[m] for m in names], dim=0))
+            sem = OrderedDict((m, ys[i * Bg:(i + 1) * Bg]) for i, m in enumerate(names))
+        else:
+            sem = OrderedDict(raw.items())
         flist = list(sem.values()); mlist = [fmask[m] for m in sem]
         if self.training:
             mlist = self._modality_dropout(list(sem.keys()), mlist)

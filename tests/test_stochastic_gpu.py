@@ -126,7 +126,8 @@ def test_model_train_regularisers():
         L = m.compute_loss(o, batch['person_id'].cuda())
         L['total_loss'].backward()
         outs.append((o['logits'].detach().clone(), m.lora_arena.grad.detach().clone(), float(L['total_loss'].detach())))
-    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]       # same seed -> same masks
+    assert torch.equal(outs[0][0], outs[1][0])                                    # same seed -> same masks -> same logits
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[1][2])                 # (the loss sums use fp32 atomics: last-bit freedom)
     assert np.isfinite(outs[0][2]) and float(outs[0][1].abs().sum()) > 0
     o2 = a(images=images, texts=batch['texts'], modality_masks=masks)             # next call: new masks
     assert not torch.equal(o2['logits'].detach(), outs[0][0])
