@@ -210,16 +210,11 @@ class Engine:
         """Per layer (s_attn, s_mlp), each f32 [n_img] = floor(keep + U) / keep with keep = 1 - rate * l / (L - 1)
         (DropPath, clip_backbone.py:137-141 with the per-block rates of :204); None where the rate is 0."""
         L = self.arch['vision_layers']
-        out = []
-        for l in range(L):
-            p = rate * l / max(1, L - 1)
-            if p <= 0.0:
-                out.append((None, None)); continue
-            keep = 1.0 - p
-            u = torch.rand(2, n_img, device=self.dev, generator=self._rng)
-            sc = torch.floor(u + keep) / keep
-            out.append((sc[0].contiguous(), sc[1].contiguous()))
-        return out
+        keep = self._const(('dp_keep', L, float(rate)),
+                           lambda: torch.tensor([1.0 - rate * l / max(1, L - 1) for l in range(L)], dtype=torch.float32))
+        u = torch.rand(L, 2, n_img, device=self.dev, generator=self._rng)          # ONE draw for all 2L branches
+        sc = torch.floor(u + keep.view(L, 1, 1)) / keep.view(L, 1, 1)
+        return [(None, None) if rate * l / max(1, L - 1) <= 0.0 else (sc[l, 0], sc[l, 1]) for l in range(L)]
 
     def vision_forward(self, groups: List[Tuple[int, torch.Tensor]], save: bool, drop_scales=None):
         """groups: [(modality index, images f32 [n,3,H,W])] -> (features f32 [n_img, D], saved state).
@@ -427,6 +422,11 @@ class Engine:
                 ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
             fork(*[(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d]) for g in range(3)],
                  (Uq, s['h'], gA(l, 'qkv')))
+            if l == 0 and not want_dense:
+                # nothing below layer 0 trains under the default freeze: the gradient of the embedded sequence (dX of the
+                # q|k|v projection and the LN1 backward) would be computed only to be thrown away
+                join()
+                break
             ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
             if want_dense:
                 gw = wgrad(dqkv, s['h']); gb_ = colsum(dqkv)

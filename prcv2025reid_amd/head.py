@@ -56,11 +56,15 @@ class LinearF32Fn(torch.autograd.Function):
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = dy.contiguous().float()
-        dx = torch.empty_like(x)
-        ops.sgemm(dy, W, dx)                                  # [B,C] @ [C,D]
-        dW = torch.empty_like(W)
-        ops.sgemm(dy, x, dW, ta=True)                         # [C,B] @ [B,D]
-        db = dy.sum(0) if ctx.has_bias else None
+        dx = dW = db = None                                   # only what autograd asks for (frozen weights cost nothing)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ops.sgemm(dy, W, dx)                              # [B,C] @ [C,D]
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            ops.sgemm(dy, x, dW, ta=True)                     # [C,B] @ [B,D]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
         return dx, dW, db
 
 
@@ -186,7 +190,8 @@ class LayerNormF32Fn(torch.autograd.Function):
         x2, w, mean, rstd = ctx.saved_tensors
         g2 = g.contiguous().float().view(x2.shape)
         dx = torch.empty_like(x2)
-        dw = torch.zeros_like(w); db = torch.zeros_like(w)
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw = torch.zeros_like(w) if want else None; db = torch.zeros_like(w) if want else None
         ops.layernorm_bwd(g2, x2, w, mean, rstd, dx, dgamma=dw, dbeta=db)
         return dx.view(ctx.shp), dw, db, None
 
@@ -209,17 +214,20 @@ class LinearNdF32Fn(torch.autograd.Function):
     def backward(ctx, g):
         x2, W = ctx.saved_tensors
         g2 = g.contiguous().float().view(x2.shape[0], W.shape[0])
-        dx = torch.empty_like(x2)
-        ops.sgemm(g2, W, dx)
-        dW = torch.empty_like(W)
-        ops.sgemm(g2, x2, dW, ta=True)
+        dx = dW = None                                        # only what autograd asks for: the SDM module and the fusion block
+        if ctx.needs_input_grad[0]:                           # are frozen under the reference's default rule (train.py:1418-1425)
+            dx = torch.empty_like(x2)
+            ops.sgemm(g2, W, dx)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            ops.sgemm(g2, x2, dW, ta=True)
         db = None
-        if ctx.has_bias:
+        if ctx.has_bias and ctx.needs_input_grad[2]:
             ones = torch.ones(1, g2.shape[0], device=g2.device)
             db = torch.empty(1, W.shape[0], device=g2.device)
             ops.sgemm(ones, g2, db)
             db = db.view(-1)
-        return dx.view(ctx.shp), dW, db
+        return (None if dx is None else dx.view(ctx.shp)), dW, db
 
 
 class SmallAttnFn(torch.autograd.Function):
