@@ -9,6 +9,7 @@
 // The row range is cut into slabs over blockIdx.z-like slices; partial tiles are combined with
 // fp32 atomics (sum order is not fixed: results can differ in the last bits between runs).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -156,7 +157,11 @@ int launch_tn(TnParams& p, hipStream_t s) {
     p.tiles_p = (p.P + BP - 1) / BP;
     p.tiles_q = (p.Q + BQ - 1) / BQ;
     const int tiles = p.tiles_p * p.tiles_q;
-    int slabs = 1536 / tiles;
+    // workgroups per launch: few, long-lived slabs (each pays its load latency once) -- 384 instead of 1536 took the small
+    // products from 30 to 22 us stand-alone and 0.6 ms off the train step (less interference with the dX GEMMs; r01 sweep 128..6144)
+    int target = 384;
+    { const char* e = getenv("REID_TN_BLOCKS"); if (e && atoi(e) > 0) target = atoi(e); }
+    int slabs = target / tiles;
     if (slabs < 1) slabs = 1;
     const int max_slabs = (p.M + 255) / 256;
     if (slabs > max_slabs) slabs = max_slabs;
