@@ -123,6 +123,7 @@ class Engine:
         self._lora_pack = None
         self._table = None
         self._side = None
+        self._tside = None
         self._consts = {}
         self._rng = torch.Generator(device=device)
         self._rng.manual_seed(777)
@@ -142,6 +143,11 @@ class Engine:
             t = make().to(self.dev)
             self._consts[key] = t
         return t
+
+    def _text_stream(self):
+        if self._tside is None:
+            self._tside = torch.cuda.Stream(self.dev)
+        return self._tside
 
     def _side_stream(self):
         if self._side is None:

@@ -28,6 +28,8 @@ import logging
 from collections import OrderedDict
 from typing import Any, Dict, List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -110,6 +112,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self._ref[LORA_PARAM_NAME] = self.lora_arena
         self.engine = Engine(self.arch, self._ref, self.lora_arena, dev)
         self._plans = {}
+        self._overlap_text = os.environ.get('REID_TEXT_STREAM', '1') != '0'
         # Stochastic regularisers of the reference's training forward (all inactive in eval mode):
         #   DropPath in the vision blocks (clip_backbone.py:137-141,204), dropout in the SDM module (hard-coded 0.1: model.py:35,43),
         #   in the fusion block (fusion_dropout: model.py:95,104,106), before the classifier (dropout_rate: model.py:200,221),
@@ -451,6 +454,21 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
                     sel = img.to(dev) if kind == 'all' else img.to(dev)[sel_idx]
                     groups.append((self.vision_modalities.index(m), sel.float()))
                     order.append((m, None if kind == 'all' else sel_idx, mask_dev))
+        # The (frozen) text tower is independent of the vision pass and made of small launches (B*T ~ 5k rows): it runs on a
+        # second HIP stream underneath the vision encoder's big GEMMs and is joined before the head.
+        n_text = 0 if texts is None else (texts['input_ids'].shape[0] if isinstance(texts, dict) else len(texts))
+        tf = None; text_ev = None
+        if texts is not None and n_text > 0:
+            ids, am = self._tokens(texts)
+            if self._overlap_text and not (torch.is_grad_enabled() and self.engine.text_trains()) and groups:
+                main = torch.cuda.current_stream(dev)
+                side = self.engine._text_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    tf = self.engine.text_forward(ids.to(dev), None if am is None else am.to(dev))
+                text_ev = torch.cuda.Event(); text_ev.record(side)
+            else:
+                tf = self._text_apply(ids, am)
         feats = None
         if groups:
             if self.training and self.drop_path > 0 and torch.is_grad_enabled():
@@ -467,10 +485,10 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
                 n = idx.shape[0]
                 full = null.expand(B, -1).clone().index_copy(0, idx, feats[start:start + n]); start += n
             raw[m] = full; fmask[m] = mask
-        n_text = 0 if texts is None else (texts['input_ids'].shape[0] if isinstance(texts, dict) else len(texts))
-        if texts is not None and n_text > 0:
-            ids, am = self._tokens(texts)
-            tf = self._text_apply(ids, am)
+        if tf is not None:
+            if text_ev is not None:
+                torch.cuda.current_stream(dev).wait_event(text_ev)
+                tf.record_stream(torch.cuda.current_stream(dev))
             tmd = plan['text'][2]
             if plan['text'][0] != 'all':
                 tf = torch.where(tmd.bool().view(B, 1), tf, self._ref['null_tokens.text'].expand(B, -1))
