@@ -131,6 +131,7 @@ class Engine:
         self.text_backward_ready = True
         self._text_packed = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
+        self.cls_prune = os.environ.get('REID_CLS_PRUNE', '1') != '0'
         self.W = {}
 
     def _const(self, key, make):
@@ -255,6 +256,8 @@ class Engine:
         pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
         saved = []
         buf = {}
+        idx = self._const(('cls_idx', n_img, S), lambda: torch.arange(n_img, dtype=torch.int32) * S)
+        idxl = self._const(('cls_idx64', n_img, S), lambda: torch.arange(n_img, dtype=torch.int64) * S)
 
         def new(name, shape, kw):
             if save:
@@ -274,37 +277,47 @@ class Engine:
             ops.gemm(h, W[('v', l, 'qkv')], qkv, A2=T, B2=pk(l, 'qkv', 'B'), K2=Rp, k2_group_n=d, bias=W[('v', l, 'bqkv')])
             o = new('o', (M, d), b16); lse = new('lse', (n_img, heads, S), f32)
             ops.attn_fwd(qkv, o, lse, n_img, S, heads)
-            To = new('To', (M, Rp), b16)
-            ops.gemm(o, pk(l, 'out', 'A'), To, **mk)
-            xm = new('xm', (M, d), f32)
             sa, sm_ = (None, None) if drop_scales is None else drop_scales[l]
-            ops.gemm(o, W[('v', l, 'out')], xm, A2=To, B2=pk(l, 'out', 'B'), K2=Rp,
-                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=x, row_scale=sa, rows_per_img=S)
-            h2 = new('h2', (M, d), b16); mean2 = new('m2', (M,), f32); rstd2 = new('r2', (M,), f32)
+            last = self.cls_prune and l == a['vision_layers'] - 1
+            if last:
+                # Only the class-token row of the last block's output is ever used (clip_backbone.py:281: x[:, 0]), and rows do
+                # not mix after the attention core: out-projection, LN2 and the MLP of the LAST block run on the n_img class rows
+                # instead of all n_img*197 (same function; the reference computes and discards the other 196/197).
+                Mr, rpi = n_img, 1
+                xin = x.index_select(0, idxl); oin = o.index_select(0, idxl)
+            else:
+                Mr, rpi = M, S
+                xin, oin = x, o
+            mkr = dict(img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=self.scaling)
+            To = new('To', (Mr, Rp), b16)
+            ops.gemm(oin, pk(l, 'out', 'A'), To, **mkr)
+            xm = new('xm', (Mr, d), f32)
+            ops.gemm(oin, W[('v', l, 'out')], xm, A2=To, B2=pk(l, 'out', 'B'), K2=Rp,
+                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=xin, row_scale=sa, rows_per_img=rpi)
+            h2 = new('h2', (Mr, d), b16); mean2 = new('m2', (Mr,), f32); rstd2 = new('r2', (Mr,), f32)
             ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
-            T1 = new('T1', (M, Rp), b16)
-            ops.gemm(h2, pk(l, 'fc1', 'A'), T1, **mk)
-            u = new('u', (M, ff), b16) if save else None
-            g = new('g', (M, ff), b16)
+            T1 = new('T1', (Mr, Rp), b16)
+            ops.gemm(h2, pk(l, 'fc1', 'A'), T1, **mkr)
+            u = new('u', (Mr, ff), b16) if save else None
+            g = new('g', (Mr, ff), b16)
             ops.gemm(h2, W[('v', l, 'fc1')], g, A2=T1, B2=pk(l, 'fc1', 'B'), K2=Rp,
                      bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu', C2=u)
-            T2 = new('T2', (M, Rp), b16)
-            ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mk)
-            xn = torch.empty(M, d, **f32) if save else new('xn' + str(l & 1), (M, d), f32)
+            T2 = new('T2', (Mr, Rp), b16)
+            ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mkr)
+            xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
             ops.gemm(g, W[('v', l, 'fc2')], xn, A2=T2, B2=pk(l, 'fc2', 'B'), K2=Rp,
-                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=S)
+                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi)
             if save:
                 saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
-                                  mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2, sa=sa, sm=sm_))
+                                  mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2, sa=sa, sm=sm_, cls=last, o_rows=oin))
             x = xn
-        idx = self._const(('cls_idx', n_img, S), lambda: torch.arange(n_img, dtype=torch.int32) * S)
         cls_h = torch.empty(n_img, d, **b16); mf = torch.empty(n_img, **f32); rf = torch.empty(n_img, **f32)
         ops.layernorm_fwd(x, P[ce + 'vision_ln_final.weight'], P[ce + 'vision_ln_final.bias'], y_bf16=cls_h, mean=mf, rstd=rf,
-                          row_index=idx)
+                          row_index=None if self.cls_prune else idx)
         feats = torch.empty(n_img, a['fusion_dim'], **f32)
         ops.gemm(cls_h, W['vproj'], feats)
-        state = dict(layers=saved, x_final=x, idx=idx, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
-                     groups=groups) if save else None
+        state = dict(layers=saved, x_final=x, idx=idx, idxl=idxl, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
+                     groups=groups, cls_prune=self.cls_prune) if save else None
         return feats, state
 
     # ------------------------------------------------------------------------------- vision backward
@@ -340,7 +353,13 @@ class Engine:
         dfb = ops.to_bf16(dfeat)
         dcls = torch.empty(n_img, d, **b16)
         ops.gemm(dfb, W['vprojT'], dcls)
-        dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
+        prune = bool(st.get('cls_prune'))
+        idxl = st['idxl']
+        if prune:                                           # class rows only until the last block's attention (see vision_forward)
+            dx = torch.empty(M, d, **f32); dxb = torch.empty(M, d, **b16)       # first written (all rows) by the last block's LN1 backward
+            dx_c = torch.empty(n_img, d, **f32); dxb_c = torch.empty(n_img, d, **b16)
+        else:
+            dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
         dense = {} if want_dense else None
         ones8 = torch.ones(M, 8, **b16) if want_dense else None
 
@@ -364,8 +383,12 @@ class Engine:
             dense[ce + 'vision_proj.weight'] = wgrad(dfb, st['cls_h'])
         dgf, dbf = ln_grads(ce + 'vision_ln_final')
         # dxb always holds the gradient ENTERING the next residual branch: dx times that branch's DropPath factor
-        ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
-                          row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S, dgamma=dgf, dbeta=dbf)
+        if prune:
+            ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx_c, dx_bf16=dxb_c,
+                              bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=1, dgamma=dgf, dbeta=dbf)
+        else:
+            ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
+                              row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S, dgamma=dgf, dbeta=dbf)
         # reusable scratch (one U per linear: the side stream still reads it while the next skinny GEMM runs)
         U2 = torch.empty(M, Rp, **b16); U1 = torch.empty(M, Rp, **b16); Uo = torch.empty(M, Rp, **b16)
         Uq = torch.empty(M, 3 * Rp, **b16)
@@ -394,31 +417,46 @@ class Engine:
         for l in reversed(range(a['vision_layers'])):
             s = st['layers'][l]
             lp = f'{ce}vision_layers.{l}.'
+            c = bool(s.get('cls'))                          # this block's MLP / out-projection ran on the class rows only
+            if c:
+                Mr = n_img
+                mkr = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=1, alpha=self.scaling)
+                gy, gyb = dx_c, dxb_c
+                U2r = torch.empty(Mr, Rp, **b16); U1r = torch.empty(Mr, Rp, **b16); Uor = torch.empty(Mr, Rp, **b16)
+                dur = torch.empty(Mr, ff, **b16); dhr = torch.empty(Mr, d, **b16); dor = torch.empty(Mr, d, **b16)
+                dxmr = torch.empty(Mr, d, **f32); dxmbr = torch.empty(Mr, d, **b16)
+                rpi = 1
+            else:
+                Mr, mkr, gy, gyb = M, mk, dx, dxb
+                U2r, U1r, Uor, dur, dhr, dor, dxmr, dxmbr, rpi = U2, U1, Uo, du, dh, do, dxm, dxmb, S
             # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
-            ops.gemm(dxb, pk(l, 'fc2', 'BT'), U2, **mk)
-            fork((dxb, s['T2'], gB(l, 'fc2')), (U2, s['g'], gA(l, 'fc2')))
-            ops.gemm(dxb, W[('v', l, 'fc2T')], du, A2=U2, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
+            ops.gemm(gyb, pk(l, 'fc2', 'BT'), U2r, **mkr)
+            fork((gyb, s['T2'], gB(l, 'fc2')), (U2r, s['g'], gA(l, 'fc2')))
+            ops.gemm(gyb, W[('v', l, 'fc2T')], dur, A2=U2r, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
             if want_dense:
-                dense[lp + 'mlp.fc2.shared_linear.weight'] = wgrad(dxb, s['g'])
-                dense[lp + 'mlp.fc2.shared_linear.bias'] = colsum(dxb)
+                dense[lp + 'mlp.fc2.shared_linear.weight'] = wgrad(gyb, s['g'])
+                dense[lp + 'mlp.fc2.shared_linear.bias'] = colsum(gyb)
             # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
-            ops.gemm(du, pk(l, 'fc1', 'BT'), U1, **mk)
-            fork((du, s['T1'], gB(l, 'fc1')), (U1, s['h2'], gA(l, 'fc1')))
-            ops.gemm(du, W[('v', l, 'fc1T')], dh, A2=U1, B2=pk(l, 'fc1', 'AT'), K2=Rp)
+            ops.gemm(dur, pk(l, 'fc1', 'BT'), U1r, **mkr)
+            fork((dur, s['T1'], gB(l, 'fc1')), (U1r, s['h2'], gA(l, 'fc1')))
+            ops.gemm(dur, W[('v', l, 'fc1T')], dhr, A2=U1r, B2=pk(l, 'fc1', 'AT'), K2=Rp)
             if want_dense:
-                dense[lp + 'mlp.fc1.shared_linear.weight'] = wgrad(du, s['h2'])
-                dense[lp + 'mlp.fc1.shared_linear.bias'] = colsum(du)
+                dense[lp + 'mlp.fc1.shared_linear.weight'] = wgrad(dur, s['h2'])
+                dense[lp + 'mlp.fc1.shared_linear.bias'] = colsum(dur)
             # ---- LN2
             dg2, db2 = ln_grads(lp + 'ln2')
-            ops.layernorm_bwd(dh, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxm, dx_bf16=dxmb, dres=dx,
-                              bf16_row_scale=s['sa'], rows_per_img=S, dgamma=dg2, dbeta=db2)
+            ops.layernorm_bwd(dhr, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxmr, dx_bf16=dxmbr, dres=gy,
+                              bf16_row_scale=s['sa'], rows_per_img=rpi, dgamma=dg2, dbeta=db2)
             # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
-            ops.gemm(dxmb, pk(l, 'out', 'BT'), Uo, **mk)
-            fork((dxmb, s['To'], gB(l, 'out')), (Uo, s['o'], gA(l, 'out')))
-            ops.gemm(dxmb, W[('v', l, 'outT')], do, A2=Uo, B2=pk(l, 'out', 'AT'), K2=Rp)
+            ops.gemm(dxmbr, pk(l, 'out', 'BT'), Uor, **mkr)
+            fork((dxmbr, s['To'], gB(l, 'out')), (Uor, s['o_rows'], gA(l, 'out')))
+            ops.gemm(dxmbr, W[('v', l, 'outT')], dor, A2=Uor, B2=pk(l, 'out', 'AT'), K2=Rp)
             if want_dense:
-                dense[lp + 'attn.out_proj.shared_linear.weight'] = wgrad(dxmb, s['o'])
-                dense[lp + 'attn.out_proj.shared_linear.bias'] = colsum(dxmb)
+                dense[lp + 'attn.out_proj.shared_linear.weight'] = wgrad(dxmbr, s['o_rows'])
+                dense[lp + 'attn.out_proj.shared_linear.bias'] = colsum(dxmbr)
+            if c:                                           # back to all rows: zero everywhere but the class rows
+                do.zero_(); do.index_copy_(0, idxl, dor)
+                dxm.zero_(); dxm.index_copy_(0, idxl, dxmr)
             # ---- attention
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
