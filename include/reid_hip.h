@@ -142,12 +142,15 @@ int reid_cls_rows(const float* cls, const float* pos0, float* x, int32_t ldx, in
  *   key_mask uint8 [n_seq, S] (1 = attend) or NULL; causal != 0 adds key <= query.
  *   out bf16 [n_seq*S, ldo]; lse f32 [n_seq, heads, S] (natural-log-sum-exp of scaled scores).
  *   bwd writes dqkv bf16 in the qkv layout.
+ *   q_tiles > 0: only the first q_tiles 32-row query tiles of every sequence are evaluated (all keys take part): rows
+ *   of out / lse beyond them are left untouched, dout is assumed zero there and dQ is written as zero -- the last ViT block,
+ *   whose output is used at the class token only (clip_backbone.py:281).
  * ------------------------------------------------------------------------------------------ */
 int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mask, void* out, int32_t ldo, float* lse,
-                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream);
+                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, int32_t q_tiles, void* stream);
 int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mask, const void* out, const void* dout,
                   int32_t ldo, const float* lse, void* dqkv, int32_t lddqkv, float* delta_ws,
-                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream);
+                  int32_t n_seq, int32_t S, int32_t heads, int32_t causal, int32_t q_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise helpers.

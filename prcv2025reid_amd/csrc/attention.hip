@@ -116,6 +116,7 @@ struct AttnParams {
     bf16_t* out; int ldo; float* lse;
     const bf16_t* dout; bf16_t* dqkv; int lddqkv; float* delta;
     int n_seq, S, heads, causal;
+    int q_tiles;  // > 0: only the first q_tiles 32-row QUERY tiles of every sequence are computed (all keys still take part)
     int dbg;     // timing experiments (REID_ATTN_DBG): 1 = no output stores, 2 = also no softmax / P.V, 3 = staging only
 };
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = gfrag(qb, p.ld, qrow, 2 * ks, lane);
     __syncthreads();
-    if (q0 >= p.S) return;   // wave-uniform; no barrier follows
+    if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) return;   // wave-uniform; no barrier follows
 
     if (p.dbg == 3) return;
     const FragOff fo = make_frag_off(lane);
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
     const bf16_t* o = p.out + row * p.ldo;
     const bf16_t* g = p.dout + row * p.ldo;
     const long seq = row / p.S, q = row % p.S;
+    if (p.q_tiles > 0 && q >= p.q_tiles * 32) return;     // query rows that take no part
     for (int h0 = 0; h0 < p.heads; h0 += 4) {
         const int col = h0 * 64 + lane * 4;
         float v = 0.f;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
     const float c = 0.125f * LOG2E;
     const int h4 = 4 * (lane >> 5);
     for (int qt = 0; qt < NT; ++qt) {
-        if (qt * 32 >= p.S) break;
+        if (qt * 32 >= p.S || (p.q_tiles > 0 && qt >= p.q_tiles)) break;
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -408,6 +410,16 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
     const float nl = -p.lse[so] * LOG2E, nd = -p.delta[so] * 0.125f;
     __syncthreads();
     if (q0 >= p.S) return;
+    if (p.q_tiles > 0 && wave >= p.q_tiles) {               // query tile left out: its dQ rows are exactly zero
+        if (qi < p.S) {
+            bf16_t* drow = p.dqkv + ((size_t)seq * p.S + qi) * p.lddqkv + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(uint2*)(drow + dt * 32 + 8 * g + 4 * (lane >> 5)) = uint2{0u, 0u};
+        }
+        return;
+    }
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     const FragOff fo = make_frag_off(lane);
     f32x16 dqt[2];
@@ -513,23 +525,23 @@ int check_common(const char* name, const void* qkv, int ld, int n_seq, int S, in
     }
 
 extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mask, void* out, int32_t ldo, float* lse,
-                             int32_t n_seq, int32_t S, int32_t heads, int32_t causal, void* stream) {
+                             int32_t n_seq, int32_t S, int32_t heads, int32_t causal, int32_t q_tiles, void* stream) {
     int rc = check_common("reid_attn_fwd", qkv, ld, n_seq, S, heads);
     if (rc) return rc;
     REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
-    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, 0};
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0};
     { const char* e = getenv("REID_ATTN_DBG"); if (e) p.dbg = atoi(e); }
     DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
 }
 
 extern "C" int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mask, const void* out, const void* dout,
                              int32_t ldo, const float* lse, void* dqkv, int32_t lddqkv, float* delta_ws, int32_t n_seq,
-                             int32_t S, int32_t heads, int32_t causal, void* stream) {
+                             int32_t S, int32_t heads, int32_t causal, int32_t q_tiles, void* stream) {
     int rc = check_common("reid_attn_bwd", qkv, ld, n_seq, S, heads);
     if (rc) return rc;
     REID_CHECK_ARG(out && dout && lse && dqkv && delta_ws, "reid_attn_bwd: null pointer");
     REID_CHECK_ARG(ldo >= heads * 64 && ldo % 8 == 0 && lddqkv >= 3 * heads * 64 && lddqkv % 4 == 0, "reid_attn_bwd: ldo/lddqkv");
     AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, (float*)lse, (const bf16_t*)dout, (bf16_t*)dqkv, lddqkv,
-                 delta_ws, n_seq, S, heads, causal, 0};
+                 delta_ws, n_seq, S, heads, causal, q_tiles, 0};
     DISPATCH_NT((S + 31) / 32, launch_bwd, p, (hipStream_t)stream)
 }

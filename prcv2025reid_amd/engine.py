@@ -276,7 +276,7 @@ class Engine:
             qkv = new('qkv', (M, 3 * d), b16)
             ops.gemm(h, W[('v', l, 'qkv')], qkv, A2=T, B2=pk(l, 'qkv', 'B'), K2=Rp, k2_group_n=d, bias=W[('v', l, 'bqkv')])
             o = new('o', (M, d), b16); lse = new('lse', (n_img, heads, S), f32)
-            ops.attn_fwd(qkv, o, lse, n_img, S, heads)
+            ops.attn_fwd(qkv, o, lse, n_img, S, heads, q_tiles=1 if (self.cls_prune and l == a['vision_layers'] - 1) else 0)
             sa, sm_ = (None, None) if drop_scales is None else drop_scales[l]
             last = self.cls_prune and l == a['vision_layers'] - 1
             if last:
@@ -458,7 +458,7 @@ class Engine:
                 do.zero_(); do.index_copy_(0, idxl, dor)
                 dxm.zero_(); dxm.index_copy_(0, idxl, dxmr)
             # ---- attention
-            ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads)
+            ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads, q_tiles=1 if c else 0)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
             bT = pk(l, 'qkv', 'BT')                         # [Rp, 3d]
             gBq = gB(l, 'qkv')                              # [3d, Rp]

@@ -132,14 +132,14 @@ def cls_rows(cls, pos0, x, n_img, tokens):
     check(lib().reid_cls_rows(ptr(cls), ptr(pos0), ptr(x), x.stride(0), n_img, tokens, x.shape[1], stream_ptr()))
 
 
-def attn_fwd(qkv, out, lse, n_seq, S, heads, causal=False, key_mask=None):
+def attn_fwd(qkv, out, lse, n_seq, S, heads, causal=False, key_mask=None, q_tiles=0):
     check(lib().reid_attn_fwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), out.stride(0), ptr(lse), n_seq, S, heads,
-                              int(causal), stream_ptr()))
+                              int(causal), int(q_tiles), stream_ptr()))
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, n_seq, S, heads, causal=False, key_mask=None):
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, n_seq, S, heads, causal=False, key_mask=None, q_tiles=0):
     check(lib().reid_attn_bwd(ptr(qkv), qkv.stride(0), ptr(key_mask), ptr(out), ptr(dout), out.stride(0), ptr(lse),
-                              ptr(dqkv), dqkv.stride(0), ptr(delta_ws), n_seq, S, heads, int(causal), stream_ptr()))
+                              ptr(dqkv), dqkv.stride(0), ptr(delta_ws), n_seq, S, heads, int(causal), int(q_tiles), stream_ptr()))
 
 
 def cast_f32_bf16(src, dst):

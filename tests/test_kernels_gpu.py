@@ -462,3 +462,25 @@ def test_sharded_gallery_single_process(ops):
         parts_i.append(i); parts_s.append(s)
     gi, gs = merge_topk(torch.stack(parts_i), torch.stack(parts_s), 10)
     assert torch.equal(gi, want_i.long()) and torch.allclose(gs, want_s)
+
+
+def test_attention_query_tile_limit(ops):
+    """q_tiles=1: the first 32 query rows equal the full kernel; with a cotangent that is zero elsewhere the backward is identical."""
+    g = torch.Generator(device='cuda').manual_seed(6)
+    n_seq, S, heads = 5, 197, 4
+    d = heads * 64
+    qkv = (torch.randn(n_seq * S, 3 * d, device='cuda', generator=g)).to(T16())
+    o_full = torch.empty(n_seq * S, d, device='cuda', dtype=T16()); lse_full = torch.empty(n_seq, heads, S, device='cuda')
+    ops.attn_fwd(qkv, o_full, lse_full, n_seq, S, heads)
+    o_lim = torch.zeros_like(o_full); lse_lim = torch.zeros_like(lse_full)
+    ops.attn_fwd(qkv, o_lim, lse_lim, n_seq, S, heads, q_tiles=1)
+    rows = (torch.arange(n_seq, device='cuda').view(-1, 1) * S + torch.arange(32, device='cuda').view(1, -1)).flatten()
+    assert torch.equal(o_lim[rows], o_full[rows]) and torch.equal(lse_lim[:, :, :32], lse_full[:, :, :32])
+    assert float(o_lim.float().abs().sum()) == float(o_full[rows].float().abs().sum())        # nothing else was written
+    do = torch.zeros(n_seq * S, d, device='cuda', dtype=T16())
+    do[torch.arange(n_seq, device='cuda') * S] = torch.randn(n_seq, d, device='cuda', generator=g).to(T16())
+    dq_full = torch.empty_like(qkv); dq_lim = torch.full_like(qkv, 7.0)
+    delta = torch.empty(n_seq, heads, S, device='cuda'); delta2 = torch.empty_like(delta)
+    ops.attn_bwd(qkv, o_full, do, lse_full, dq_full, delta, n_seq, S, heads)
+    ops.attn_bwd(qkv, o_lim, do, lse_lim, dq_lim, delta2, n_seq, S, heads, q_tiles=1)
+    assert torch.equal(dq_lim, dq_full)
