@@ -32,10 +32,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // swizzle is applied to the SOURCE chunk.  Rows >= S repeat row S-1 (finite values): every consumer masks them (padded
 // keys get probability 0, padded queries get P = 0 through lse = +inf), so no zero fill is needed.
 template <int NT>
-__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ base, int ld, int S, char* lds, int wave, int lane) {
+__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ base, int ld, int S, char* lds, int wave, int lane,
+                                           int row_limit = 1 << 30) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rblk = (i * NT + wave) * 8;
+        if (rblk >= row_limit) continue;                    // (wave-uniform) rows nobody will read: query tiles left out by q_tiles
         const int row = rblk + (lane >> 3);
         const int c = swz(row, lane & 7);
         const int grow = row < S ? row : S - 1;
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
     const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
-    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane);
-    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane);
+    const int q_rows = p.q_tiles > 0 ? p.q_tiles * 32 : NT * 32;
+    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane, q_rows);
+    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane, q_rows);
     for (int t = tid; t < NT * 32; t += NT * 64) {
         const size_t o = ((size_t)seq * p.heads + head) * p.S + t;
         rowc[t] = t < p.S ? -p.lse[o] * LOG2E : -INFINITY;          // exp2(s*c + rowc) = P; padded queries give 0
