@@ -122,6 +122,22 @@ struct AttnParams {
     int dbg;     // timing experiments (REID_ATTN_DBG): 1 = no output stores, 2 = also no softmax / P.V, 3 = staging only
 };
 
+// A 32x32 MFMA result tile holds, for the row on lanes l and l+32, the two 4-element halves of every 8-element column
+// group.  One v_permlane32_swap per packed dword regroups a PAIR of groups so that lane l owns group 2j whole and lane
+// l+32 group 2j+1: 16-byte stores instead of 8-byte ones.  All 64 lanes must be active.
+__device__ __forceinline__ void store_tile_row16(bf16_t* row, bool ok, const f32x16& t, float scale, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int a = 8 * j, b = 8 * j + 4;
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(t[a] * scale, t[a + 1] * scale),
+                                                         pack_bf16x2(t[b] * scale, t[b + 1] * scale), false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(t[a + 2] * scale, t[a + 3] * scale),
+                                                         pack_bf16x2(t[b + 2] * scale, t[b + 3] * scale), false, false);
+        if (ok) *(uint4*)(row + 8 * (2 * j + (lane >> 5))) = uint4{r0[0], r1[0], r0[1], r1[1]};
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------ forward
 // TWO_PASS (long sequences): the score tiles are NOT kept in registers.  Pass 1 computes them for the row maximum only,
 // pass 2 recomputes each tile, exponentiates it and feeds it straight into the P.V MFMAs.  The 28 extra MFMAs per wave
@@ -243,18 +259,12 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
     }
     l += __shfl_xor(l, 32, 64);
     if (p.dbg >= 1 && l != 12345.678f) return;
-    if (qi < p.S) {
+    {
         const float inv = 1.0f / l;
-        bf16_t* orow = p.out + ((size_t)seq * p.S + qi) * p.ldo + head * 64;
+        bf16_t* orow = p.out + ((size_t)seq * p.S + qrow) * p.ldo + head * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
-                *(uint2*)(orow + dd) = uint2{pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv),
-                                             pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv)};
-            }
-        if (p.lse && lane < 32) p.lse[((size_t)seq * p.heads + head) * p.S + qi] = mx * 0.125f + logf(l);
+        for (int dt = 0; dt < 2; ++dt) store_tile_row16(orow + dt * 32, qi < p.S, ot[dt], inv, lane);
+        if (qi < p.S && p.lse && lane < 32) p.lse[((size_t)seq * p.heads + head) * p.S + qi] = mx * 0.125f + logf(l);
     }
 }
 
@@ -371,16 +381,14 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
 #pragma unroll
             for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
     }
-    if (ki < p.S) {
-        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + ki) * p.lddqkv + head * 64;
+    {
+        const bool ok = ki < p.S;
+        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + (ok ? ki : 0)) * p.lddqkv + head * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
-                *(uint2*)(drow + d + dd) = uint2{pack_bf16x2(dkt[dt][4 * g], dkt[dt][4 * g + 1]), pack_bf16x2(dkt[dt][4 * g + 2], dkt[dt][4 * g + 3])};
-                *(uint2*)(drow + 2 * d + dd) = uint2{pack_bf16x2(dvt[dt][4 * g], dvt[dt][4 * g + 1]), pack_bf16x2(dvt[dt][4 * g + 2], dvt[dt][4 * g + 3])};
-            }
+        for (int dt = 0; dt < 2; ++dt) {
+            store_tile_row16(drow + d + dt * 32, ok, dkt[dt], 1.0f, lane);
+            store_tile_row16(drow + 2 * d + dt * 32, ok, dvt[dt], 1.0f, lane);
+        }
     }
 }
 
@@ -464,15 +472,11 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
             for (int dt = 0; dt < 2; ++dt) dqt[dt] = mfma32(col_frag_o(Ks, kt * 32 + 16 * s2, dt, fo), df, dqt[dt]);
         }
     }
-    if (qi < p.S) {
-        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + qi) * p.lddqkv + head * 64;
+    {
+        const bool ok = qi < p.S;
+        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + (ok ? qi : 0)) * p.lddqkv + head * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = dt * 32 + 8 * g + 4 * (lane >> 5);
-                *(uint2*)(drow + dd) = uint2{pack_bf16x2(dqt[dt][4 * g], dqt[dt][4 * g + 1]), pack_bf16x2(dqt[dt][4 * g + 2], dqt[dt][4 * g + 3])};
-            }
+        for (int dt = 0; dt < 2; ++dt) store_tile_row16(drow + dt * 32, ok, dqt[dt], 1.0f, lane);
     }
 }
 
