@@ -147,6 +147,40 @@ def retrieval_bench(dev):
     return out
 
 
+def encode_bench(model, dev, arch):
+    """Feature extraction of the evaluation protocol (tools/eval_mm_protocol.py:300-398): gallery = RGB images, queries =
+    modality combinations; eval mode, no autograd.  Reported next to the retrieval numbers because end-to-end
+    "eval queries/sec" is bounded by whichever of (encode, rank) is slower."""
+    was_training = model.training
+    model.eval()
+    g = torch.Generator(device=dev).manual_seed(3)
+    out = {}
+    H = arch['image_size']
+    cases = {'gallery_vis_b256': (['vis'], False, 256), 'query_quad_nir_sk_cp_text_b64': (['nir', 'sk', 'cp'], True, 64),
+             'query_single_sk_b256': (['sk'], False, 256)}
+    with torch.no_grad():
+        for name, (mods, text, B) in cases.items():
+            images = {m: torch.randn(B, 3, H, H, device=dev, generator=g) for m in mods}
+            masks = {m: torch.ones(B) for m in mods}
+            tokens = None
+            if text:
+                tok = model.tokenizer(['a person walking'] * B, return_tensors='pt', padding=True, truncation=True, max_length=77)
+                tokens = {k: v.to(dev) for k, v in tok.items()}
+                masks['text'] = torch.ones(B)
+            for _ in range(2):
+                f = model(images=images, texts=tokens, modality_masks=masks, return_features=True)
+            torch.cuda.synchronize()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f = model(images=images, texts=tokens, modality_masks=masks, return_features=True)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / reps
+            out[name] = {'rows_per_s': B / t, 'ms': t * 1e3, 'batch': B}
+    model.train(was_training)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -299,6 +333,7 @@ def main():
             torch.cuda.empty_cache()
             log(f'train: {value:.1f} instances/s; retrieval bench')
             res['retrieval'] = retrieval_bench(dev)
+            res['retrieval']['encode'] = encode_bench(model, dev, model.arch)
             log(f'retrieval: {res["retrieval"]["queries_per_s"]:.0f} q/s')
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
