@@ -243,6 +243,15 @@ int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, co
 int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
                            const int32_t* exclude_q, const int32_t* exclude_g, float* scratch, int32_t* out_idx,
                            float* out_score, void* stream);
+/* The reference's one-query-at-a-time form (tools/eval_mm_protocol.py:401-455: sim = q @ G.T; argsort) for a handful of
+ * queries: ONE pass over the fp32 gallery (Ng*D*4 bytes, HBM-bound) instead of the batched pipeline's launch chain.  Same
+ * fp32 scores and the same (score desc, index asc) lists as reid_cosine_topk.  Allowed when reid_topk_stream_ok() returns 1
+ * (Nq <= 4, k <= 32, D a multiple of 256 up to 1024).  ws: reid_topk_stream_ws_bytes(k). */
+int32_t reid_topk_stream_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k);
+int64_t reid_topk_stream_ws_bytes(int32_t k);
+int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                            const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
+                            float* out_score, void* stream);
 /* fp32 C[M,N] = act(alpha * op(A).op(B) + bias[n]) + beta*C on the vector ALU with arbitrary element strides
  * (A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]); the small exact GEMMs of the head
  * (models/model.py:57-77,152-162) and of the SDM loss. */

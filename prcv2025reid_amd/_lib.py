@@ -41,6 +41,7 @@ EXPORTS = [
     'reid_eltwise_f32', 'reid_small_attn_fwd', 'reid_small_attn_bwd', 'reid_masked_mean',
     'reid_opt_entry_bytes', 'reid_opt_ws_floats', 'reid_opt_state_floats', 'reid_opt_sumsq', 'reid_opt_clip', 'reid_opt_adamw',
     'reid_rank_metrics', 'reid_scatter_add_rows_f32',
+    'reid_topk_stream_ok', 'reid_topk_stream_ws_bytes', 'reid_cosine_topk_stream',
 ]
 
 
@@ -81,6 +82,7 @@ def lib():
             raise ReidHipError(f'{path} lacks symbols {missing}: stale build, run `python -m prcv2025reid_amd.build --force`')
         h.reid_sdm_ws_floats.restype = C.c_int64
         h.reid_topk_ws_bytes.restype = C.c_int64
+        h.reid_topk_stream_ws_bytes.restype = C.c_int64
         if h.reid_flavor() != (1 if _flavor == 'f16' else 0):
             raise ReidHipError(f'{path} was built for the other 16-bit flavor')
         _libs[_flavor] = h

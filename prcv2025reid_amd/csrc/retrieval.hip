@@ -232,6 +232,17 @@ __global__ __launch_bounds__(256) void kth_fast_kernel(const float* __restrict__
     if (lane == 0) thr[q] = (n < k ? -INFINITY : kth - 2.f * EPS_BF16);
 }
 
+// The fp32 score of a (query, gallery row) pair is DEFINED by this evaluation order (explicit fma chain: the compiler has no
+// contraction freedom), lane l taking elements 4l + 256 j, then the xor butterfly of wave_sum.  Every path that produces a final
+// score (select_kernel, the brute-force fallback, the streaming form) uses it, so they agree bit for bit.
+__device__ __forceinline__ float dot4_acc(float s, const f32x4 a, const f32x4 b) {
+    float t = a[0] * b[0];
+    t = __builtin_fmaf(a[1], b[1], t);
+    t = __builtin_fmaf(a[2], b[2], t);
+    t = __builtin_fmaf(a[3], b[3], t);
+    return s + t;
+}
+
 // phase C: exact fp32 re-score of the candidates + top-k by (score desc, index asc)
 __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int D,
                                                      const int32_t* __restrict__ exq, const int32_t* __restrict__ exg,
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Q
         float s = 0.f;
         for (int i = lane * 4; i < D; i += 256) {
             const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
-            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            s = dot4_acc(s, a, b);
         }
         s = wave_sum(s);
         if (eq >= 0 && exg[gi] == eq) s = -1e9f;
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) void brute_score_kernel(const float* __restric
         float s = 0.f;
         for (int i = lane * 4; i < D; i += 256) {
             const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
-            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            s = dot4_acc(s, a, b);
         }
         s = wave_sum(s);
         if (eq >= 0 && exg[gi] == eq) s = -1e9f;
@@ -471,6 +482,239 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     if (!attr3) { (void)hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 1024 * 4); attr3 = true; }
     hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt, cap, k, out_idx, out_score, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(select)");
+    return REID_OK;
+}
+
+// ------------------------------------------------------------------------------------------ streaming form (a few queries)
+// The reference ranks ONE query at a time (tools/eval_mm_protocol.py:401-455: sim = q @ G.T, argsort).  For a handful of
+// queries the batched pipeline above is all launch latency (sample, threshold, filter, select: ~190 us at Nq = 1) although
+// the problem is one pass over the gallery.  Here: ONE kernel streams the fp32 gallery once (Ng*D*4 bytes, HBM-bound), scores
+// up to SQ queries per row with the very arithmetic of select_kernel's re-score (so both paths produce the same fp32
+// scores, bit for bit), and keeps a k-entry list per wave and query in LDS (replace-the-worst; after the first few rows
+// almost no row qualifies).  A second, small kernel merges the per-workgroup lists.  Order: score descending, gallery index
+// ascending on ties, as everywhere.
+namespace {
+constexpr int SQ = 4;               // queries per pass over the gallery
+constexpr int STREAM_K_MAX = 32;    // a sort window of 64 lanes holds the best k plus at least as many new entries
+constexpr int STREAM_LIST_BUDGET = 16384;   // list entries per query over all workgroups (bounds the merge pass and the workspace)
+
+__device__ __forceinline__ bool ranks_before(float sa, int ia, float sb, int ib) { return sa > sb || (sa == sb && ia < ib); }
+
+inline int stream_groups(int k) {
+    int g = STREAM_LIST_BUDGET / k;
+    return g > 1024 ? 1024 : g;
+}
+
+// A wave's candidates of one query live in REGISTERS, one entry per lane: appending is two v_cndmask (no LDS, no shuffles).
+// When all 64 lanes are taken, the entries are ranked against each other (64 readlane broadcasts), moved to the lane of their
+// rank with one ds_permute -- i.e. sorted -- and everything behind rank k is dropped; the k-th entry becomes the bar a row has
+// to clear from then on.  Rows that clear the bar get rarer as the scan proceeds (~k ln(rows/k) in total).
+struct LaneList { float s; int i; };
+constexpr int INVALID_IDX0 = 0x7fffffc0;     // 64 distinct "after everything" keys for unused lanes
+
+// sort the wave's entries best-first across the lanes; entries of lanes >= cnt or with a negative index are void and end up
+// last.  Returns the number of real entries.
+__device__ __forceinline__ int lanelist_sort(LaneList& e, int cnt, int lane) {
+    const bool real = lane < cnt && e.i >= 0;
+    const float ms = real ? e.s : -INFINITY;
+    const int mi = real ? e.i : INVALID_IDX0 + lane;
+    int rank = 0;
+#pragma unroll
+    for (int m = 0; m < 64; ++m) {
+        const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), m));
+        const int oi = __builtin_amdgcn_readlane(mi, m);
+        rank += ranks_before(os, oi, ms, mi) ? 1 : 0;
+    }
+    e.s = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(rank * 4, __builtin_bit_cast(int, ms)));
+    e.i = __builtin_amdgcn_ds_permute(rank * 4, mi);
+    return __builtin_popcountll(__ballot(real));
+}
+
+// the k best of n entries in LDS (void entries: index < 0), sorted into lanes [0, k) of the calling wave; k <= STREAM_K_MAX <= 32:
+// a window of 64 lanes = the best k so far + up to 64 - k new entries per sort
+__device__ __forceinline__ int wave_select_lds(const float* sc, const int32_t* ix, int n, int k, int lane, LaneList& e) {
+    int have = n < 64 ? n : 64;
+    e = lane < have ? LaneList{sc[lane], ix[lane]} : LaneList{-INFINITY, -1};
+    int next = have;
+    int real = lanelist_sort(e, have, lane);
+    while (next < n) {
+        const int keep = real < k ? real : k;
+        const int take = (n - next) < (64 - keep) ? (n - next) : (64 - keep);
+        if (lane >= keep && lane < keep + take) e = LaneList{sc[next + lane - keep], ix[next + lane - keep]};
+        next += take;
+        real = lanelist_sort(e, keep + take, lane);
+    }
+    return real < k ? real : k;
+}
+
+template <int DJ, int STREAM_ROWS>      // D = 256 * DJ
+__global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng,
+                                                          const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int nq,
+                                                          int k, float* __restrict__ part_score, int32_t* __restrict__ part_idx) {
+    constexpr int D = 256 * DJ;
+    __shared__ float lsc[SQ][4][STREAM_K_MAX];
+    __shared__ int32_t lix[SQ][4][STREAM_K_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    f32x4 qv[SQ][DJ];
+    int eq[SQ];
+    LaneList list[SQ];
+    int cnt[SQ]; float bar_s[SQ]; int bar_i[SQ];           // wave-uniform
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        const int qq = q < nq ? q : nq - 1;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) qv[q][j] = *(const f32x4*)(Qf + (size_t)qq * D + lane * 4 + 256 * j);
+        eq[q] = exq ? exq[qq] : -1;
+        list[q] = LaneList{-INFINITY, -1};
+        cnt[q] = 0; bar_s[q] = -INFINITY; bar_i[q] = 0x7fffffff;
+    }
+    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + w;
+    for (long base = (long)gw * STREAM_ROWS; base < Ng; base += (long)nwaves * STREAM_ROWS) {
+        f32x4 gv[STREAM_ROWS][DJ];
+#pragma unroll
+        for (int r = 0; r < STREAM_ROWS; ++r) {
+            const long row = base + r < Ng ? base + r : Ng - 1;
+#pragma unroll
+            for (int j = 0; j < DJ; ++j) gv[r][j] = __builtin_nontemporal_load((const f32x4*)(Gf + (size_t)row * D + lane * 4 + 256 * j));
+        }
+#pragma unroll
+        for (int r = 0; r < STREAM_ROWS; ++r) {
+            const int row = (int)(base + r);
+            if (row >= Ng) break;                                   // wave-uniform
+            const int eg = exg ? exg[row] : -2;
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
+                if (q >= nq) break;
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < DJ; ++j) s = dot4_acc(s, qv[q][j], gv[r][j]);      // the arithmetic of select_kernel, term for term
+                s = wave_sum(s);                                    // the same bits in every lane (commutative butterfly)
+                s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+                if (eq[q] >= 0 && eg == eq[q]) s = -1e9f;
+                if (ranks_before(s, row, bar_s[q], bar_i[q])) {     // scalar branch
+                    if (lane == cnt[q]) { list[q].s = s; list[q].i = row; }
+                    if (++cnt[q] == 64) {
+                        lanelist_sort(list[q], 64, lane);
+                        cnt[q] = k;
+                        bar_s[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, list[q].s), k - 1));
+                        bar_i[q] = __builtin_amdgcn_readlane(list[q].i, k - 1);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        if (q >= nq) break;
+        lanelist_sort(list[q], cnt[q], lane);
+        if (lane < STREAM_K_MAX) {
+            const bool ok = lane < cnt[q] && lane < k;
+            lsc[q][w][lane] = ok ? list[q].s : -INFINITY;
+            lix[q][w][lane] = ok ? list[q].i : -1;
+        }
+    }
+    __syncthreads();
+    // the workgroup's list of each query = best k of its four wave lists; wave q takes query q
+    if (w < nq) {
+        LaneList e;
+        const int real = wave_select_lds(&lsc[w][0][0], &lix[w][0][0], 4 * STREAM_K_MAX, k, lane, e);
+        if (lane < k) {
+            part_score[((size_t)w * gridDim.x + blockIdx.x) * k + lane] = lane < real ? e.s : -INFINITY;
+            part_idx[((size_t)w * gridDim.x + blockIdx.x) * k + lane] = lane < real ? e.i : -1;
+        }
+    }
+}
+
+// One workgroup per query merges the workgroups' lists, each sorted best-first.  The k-th best of 64 list heads (the best head
+// each lane sees) is a bar no result can rank behind, and only lists whose head clears it can hold entries that do: one pass
+// over the lists leaves a few dozen survivors in LDS (n in the worst case: the buffer holds them all), from which one wave
+// takes the k best.
+__global__ __launch_bounds__(256) void stream_merge_kernel(const float* __restrict__ part_score, const int32_t* __restrict__ part_idx,
+                                                           int groups, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    extern __shared__ char smm[];
+    const int n = groups * k;
+    float* sc = (float*)smm;
+    int32_t* ix = (int32_t*)(sc + n);
+    __shared__ int lcnt;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* ps = part_score + (size_t)q * n;
+    const int32_t* pi = part_idx + (size_t)q * n;
+    if (tid == 0) lcnt = 0;
+    // every wave derives the bar for itself (no cross-wave exchange)
+    LaneList hb{-INFINITY, -1};
+    for (int g = lane; g < groups; g += 64) {
+        const float hs = ps[(size_t)g * k]; const int hi = pi[(size_t)g * k];
+        if (hi >= 0 && (hb.i < 0 || ranks_before(hs, hi, hb.s, hb.i))) hb = LaneList{hs, hi};
+    }
+    const int nh = lanelist_sort(hb, 64, lane);
+    float bar_s = -INFINITY; int bar_i = 0x7fffffff;                // fewer than k non-empty lanes: no bar
+    if (nh >= k) {
+        bar_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hb.s), k - 1));
+        bar_i = __builtin_amdgcn_readlane(hb.i, k - 1);
+    }
+    __syncthreads();
+    for (int g = tid; g < groups; g += 256) {
+        const float* ls = ps + (size_t)g * k; const int32_t* li = pi + (size_t)g * k;
+        for (int c = 0; c < k; ++c) {                               // lists are sorted: stop at the first entry behind the bar
+            const float s = ls[c]; const int gi = li[c];
+            if (gi < 0 || ranks_before(bar_s, bar_i, s, gi)) break;
+            const int pos = atomicAdd(&lcnt, 1);
+            sc[pos] = s; ix[pos] = gi;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    LaneList e;
+    const int real = wave_select_lds(sc, ix, lcnt, k, lane, e);
+    if (lane < k) {
+        out_idx[(size_t)q * k + lane] = lane < real ? e.i : -1;
+        out_score[(size_t)q * k + lane] = lane < real ? e.s : -INFINITY;
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t reid_topk_stream_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k) {
+    return Nq >= 1 && Nq <= SQ && k >= 1 && k <= STREAM_K_MAX && k <= Ng && D % 256 == 0 && D >= 256 && D <= 1024 && Ng >= 1;
+}
+extern "C" int64_t reid_topk_stream_ws_bytes(int32_t k) { return (int64_t)SQ * stream_groups(k) * k * 8; }
+
+/* Top-k of a few queries in ONE pass over the fp32 gallery (the reference's one-query-at-a-time form).  Same results as
+ * reid_cosine_topk; allowed when reid_topk_stream_ok().  ws: reid_topk_stream_ws_bytes(k). */
+extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                                       const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
+                                       float* out_score, void* stream) {
+    REID_CHECK_ARG(Qf && Gf && ws && out_idx && out_score, "reid_cosine_topk_stream: null pointer");
+    REID_CHECK_ARG(reid_topk_stream_ok(Nq, Ng, D, k), "reid_cosine_topk_stream: Nq=%d Ng=%d D=%d k=%d outside the streaming form", Nq, Ng, D, k);
+    REID_CHECK_ARG((exclude_q == nullptr) == (exclude_g == nullptr), "reid_cosine_topk_stream: exclude_q and exclude_g go together");
+    REID_CHECK_ARG((((uintptr_t)Qf | (uintptr_t)Gf) & 15) == 0, "reid_cosine_topk_stream: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int groups = stream_groups(k);
+    const int need = (Ng + 15) / 16;        // no more workgroups than there is work
+    if (groups > need) groups = need;
+    float* ps = (float*)ws;
+    int32_t* pi = (int32_t*)(ps + (size_t)SQ * groups * k);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)stream_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LIST_BUDGET * 8); attr = true; }
+    for (int q0 = 0; q0 < Nq; q0 += SQ) {
+        const int nq = Nq - q0 < SQ ? Nq - q0 : SQ;
+        const float* Q = Qf + (size_t)q0 * D;
+        const int32_t* eq = exclude_q ? exclude_q + q0 : nullptr;
+        // gallery rows per wave and iteration (the loads of all rows are issued before the first dot): 4 rows = 8 KiB in flight per wave at D = 512
+        static const int rows_env = [] { const char* e = getenv("REID_STREAM_ROWS"); return e ? atoi(e) : 0; }();
+#define REID_STREAM_LAUNCH(DJ, R) hipLaunchKernelGGL((stream_topk_kernel<DJ, R>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
+        switch (D / 256) {
+            case 1: REID_STREAM_LAUNCH(1, 4); break;
+            case 2: if (rows_env == 2) REID_STREAM_LAUNCH(2, 2); else if (rows_env == 8) REID_STREAM_LAUNCH(2, 8); else REID_STREAM_LAUNCH(2, 4); break;
+            case 3: REID_STREAM_LAUNCH(3, 2); break;
+            default: REID_STREAM_LAUNCH(4, 2); break;
+        }
+#undef REID_STREAM_LAUNCH
+        REID_CHECK_LAUNCH("reid_cosine_topk_stream(scan)");
+        hipLaunchKernelGGL(stream_merge_kernel, dim3(nq), dim3(256), (size_t)groups * k * 8, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
+                           out_score + (size_t)q0 * k);
+        REID_CHECK_LAUNCH("reid_cosine_topk_stream(merge)");
+    }
     return REID_OK;
 }
 

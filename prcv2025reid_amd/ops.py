@@ -253,6 +253,19 @@ def cosine_topk(Qb, Gb, Qf, Gf, k, ws, out_idx, out_score, exclude_q=None, exclu
                                  ptr(exclude_q), ptr(exclude_g), ptr(ws), ptr(out_idx), ptr(out_score), stream_ptr()))
 
 
+def topk_stream_ok(Nq, Ng, D, k) -> bool:
+    return bool(lib().reid_topk_stream_ok(Nq, Ng, D, k))
+
+
+def topk_stream_ws_bytes(k):
+    return int(lib().reid_topk_stream_ws_bytes(k))
+
+
+def cosine_topk_stream(Qf, Gf, k, ws, out_idx, out_score, exclude_q=None, exclude_g=None):
+    check(lib().reid_cosine_topk_stream(ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k, ptr(exclude_q), ptr(exclude_g),
+                                        ptr(ws), ptr(out_idx), ptr(out_score), stream_ptr()))
+
+
 def cosine_topk_exact(Qf, Gf, k, scratch, out_idx, out_score, exclude_q=None, exclude_g=None):
     check(lib().reid_cosine_topk_exact(ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k, ptr(exclude_q),
                                        ptr(exclude_g), ptr(scratch), ptr(out_idx), ptr(out_score), stream_ptr()))

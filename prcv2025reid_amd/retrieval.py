@@ -32,22 +32,34 @@ class GalleryIndex:
         self._ws = None
 
     def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False,
-             query_img_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+             query_img_ids: Optional[torch.Tensor] = None, stream: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(indices int32 [Nq, k], scores f32 [Nq, k]); entries whose img id equals the query's are excluded
-        (same-image mask of eval_mm_protocol.py:421-422) when both id vectors are given."""
+        (same-image mask of eval_mm_protocol.py:421-422) when both id vectors are given.  ``stream``: force the one-pass
+        form for a few queries (True) or the batched MFMA pipeline (False); default: whichever fits the shape."""
         Qf = queries.contiguous().float()
         if not normalized:
             Qf = l2_normalize(Qf)
-        Qb = ops.to_t16(Qf)
         Nq, Ng = Qf.shape[0], self.Gf.shape[0]
+        exq = exg = None
+        if query_img_ids is not None and self.img_ids is not None:
+            exq = query_img_ids.to(Qf.device, torch.int32).contiguous(); exg = self.img_ids
+        if stream is None:
+            stream = ops.topk_stream_ok(Nq, Ng, Qf.shape[1], k)
+        if stream:
+            # a handful of queries: one pass over the fp32 gallery (the reference's per-query form), no host sync
+            need = ops.topk_stream_ws_bytes(k)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=Qf.device)
+            idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
+            sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
+            ops.cosine_topk_stream(Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
+            return idx, sc
+        Qb = ops.to_t16(Qf)
         need = ops.topk_ws_bytes(Nq, Ng, k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=Qf.device)
         idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
         sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
-        exq = exg = None
-        if query_img_ids is not None and self.img_ids is not None:
-            exq = query_img_ids.to(Qf.device, torch.int32).contiguous(); exg = self.img_ids
         ops.cosine_topk(Qb, self.Gb, Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
         flagged = (idx[:, 0] == -2)
         if bool(flagged.any()):        # candidate-list overflow (thousands of near-ties): exact fp32 pass for those queries
