@@ -663,20 +663,30 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __rest
 }
 
 // out[b,:] = sum_m mask[b,m] x[b,m,:] / max(sum_m mask[b,m], 1)   (model.py:168-178);  bwd: dx[b,m,:] = mask[b,m] dout[b,:] / cnt
-__global__ void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int B, int M, int D, int bwd) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * D) return;
-    const int b = i / D, c = i % D;
-    float cnt = 0.f;
-    for (int m = 0; m < M; ++m) cnt += mask[b * M + m];
-    cnt = fmaxf(cnt, 1.f);
+// One workgroup per (b, 64 columns): thread = (column, one of 4 interleaved m-lanes), partials combined through LDS in a fixed
+// order.  M is 5 (fusion slots) or B*M (the global mean of the valid rows for all-masked samples, model.py:141-149: M = 320).
+__global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
+                                                          int B, int M, int D, int bwd) {
+    __shared__ float pc[4][64], ps[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, ml = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cok = c < D;
+    const float* mk = mask + (size_t)b * M;
+    float cnt = 0.f, s = 0.f;
+    for (int m = ml; m < M; m += 4) {
+        const float w = mk[m];
+        cnt += w;
+        if (!bwd && cok) s += w * x[((size_t)b * M + m) * D + c];
+    }
+    pc[ml][cl] = cnt; ps[ml][cl] = s;
+    __syncthreads();
+    cnt = fmaxf((pc[0][cl] + pc[1][cl]) + (pc[2][cl] + pc[3][cl]), 1.f);
+    if (!cok) return;
     if (!bwd) {
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s += mask[b * M + m] * x[((size_t)b * M + m) * D + c];
-        out[i] = s / cnt;
+        if (ml == 0) out[(size_t)b * D + c] = ((ps[0][cl] + ps[1][cl]) + (ps[2][cl] + ps[3][cl])) / cnt;
     } else {
-        const float g = x[i] / cnt;      // x = dout [B, D]
-        for (int m = 0; m < M; ++m) out[((size_t)b * M + m) * D + c] = mask[b * M + m] * g;
+        const float g = x[(size_t)b * D + c] / cnt;      // x = dout [B, D]
+        for (int m = ml; m < M; m += 4) out[((size_t)b * M + m) * D + c] = mk[m] * g;
     }
 }
 
@@ -859,8 +869,8 @@ extern "C" int reid_small_attn_bwd(const float* qkv, int32_t ld, const float* pr
 
 extern "C" int reid_masked_mean(const float* x, const float* mask, float* out, int32_t B, int32_t M, int32_t D, int32_t backward, void* stream) {
     REID_CHECK_ARG(x && mask && out && B > 0 && M > 0 && D > 0, "reid_masked_mean: bad args");
-    const long n = (long)B * D;
-    hipLaunchKernelGGL(masked_mean_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mask, out, B, M, D, backward);
+    REID_CHECK_ARG(B <= 65535, "reid_masked_mean: B");
+    hipLaunchKernelGGL(masked_mean_kernel, dim3((D + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, mask, out, B, M, D, backward);
     REID_CHECK_LAUNCH("reid_masked_mean");
     return REID_OK;
 }

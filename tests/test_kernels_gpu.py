@@ -434,6 +434,13 @@ def test_small_head_kernels(ops):
     assert rel_err(mm.detach(), refmm) < 1e-6
     mm.sum().backward()
     assert rel_err(x.grad, (mk / mk.sum(1, keepdim=True).clamp(min=1)).unsqueeze(-1).expand(B, M, D)) < 1e-6
+    # the long form: one "sample" of 323 rows (global mean of the valid rows, model.py:141-149), D not a multiple of 64
+    xl = torch.randn(1, 323, 200, device='cuda', generator=g).requires_grad_(True)
+    ml = (torch.rand(1, 323, device='cuda', generator=g) > 0.5).float()
+    mml = H.MaskedMeanFn.apply(xl, ml)
+    assert rel_err(mml.detach(), (xl.detach() * ml.unsqueeze(-1)).sum(1) / ml.sum(1, keepdim=True)) < 1e-6
+    (mml * 2.0).sum().backward()
+    assert rel_err(xl.grad, (2.0 * ml / ml.sum(1, keepdim=True)).unsqueeze(-1).expand(1, 323, 200)) < 1e-6
     for kind, fn in (('relu', torch.relu), ('gelu', torch.nn.functional.gelu)):
         a = torch.randn(300, 512, device='cuda', generator=g).requires_grad_(True)
         b2 = a.detach().clone().requires_grad_(True)
