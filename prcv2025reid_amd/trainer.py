@@ -219,6 +219,18 @@ class GraphedStep:
         self.opt.state[16] = float(self.opt.step_count)  # device-side step / batch counters take over from the host's
         self.opt.state[19] = float(driver.batch_idx)
         self.graph = torch.cuda.CUDAGraph()
+        # The training regularisers draw from this package's own device generators (DropPath per image, dropout multipliers):
+        # registered with the graph, their Philox offsets advance on every replay, so each replayed step gets fresh masks.
+        model = getattr(driver.module, 'model', driver.module)
+        for gen in (getattr(model, '_rng_head', None), getattr(getattr(model, 'engine', None), '_rng', None)):
+            if gen is not None and gen.device.type == 'cuda':
+                self.graph.register_generator_state(gen)
+        # Modality dropout decides on the HOST which modalities to drop (one draw each, as the reference does): a captured step
+        # would replay the captured decision for ever.
+        cfg = getattr(model, 'config', None)
+        if (getattr(model, 'training', False) and float(getattr(cfg, 'modality_dropout', 0.0)) > 0
+                and getattr(model, 'current_epoch', 0) > int(getattr(cfg, 'modality_dropout_warmup_epochs', 3))):
+            raise ValueError('modality dropout is active (host-side draw per step): use the eager StepDriver')
         with torch.cuda.graph(self.graph):
             self.out = self._run(True)
         self.opt.step_count -= 1                         # the capture pass recorded the launches, it did not execute them

@@ -148,3 +148,33 @@ def test_graphed_step_matches_eager():
     with pytest.raises(ValueError):
         bad = dict(masks); bad['nir'] = torch.zeros_like(masks['nir'])
         g.step(images, tok, bad, labels)
+
+
+def test_graphed_step_with_training_regularisers():
+    """DropPath / dropout masks come from this package's device generators: registered with the graph, every replay draws
+    fresh ones (two replays on identical inputs and weights-frozen-in-place give different losses); active modality dropout
+    (a host-side draw) is refused."""
+    from prcv2025reid_amd.trainer import FusedAdamW, StepDriver, GraphedStep
+    from test_model_gpu import build_model
+    z, meta = load_case('tiny_train_frozen')
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    images = {m: t.cuda() for m, t in batch['images'].items()}
+    masks = dict(batch['modality_mask'])
+    labels = batch['person_id'].cuda()
+    m = build_model(meta, state, True)
+    m.drop_path = 0.3; m.dropout_rate = 0.5; m.fusion_dropout = 0.1; m.sdm_dropout = 0.1
+    m.seed_stochastic(5)
+    gs = [dict(params=[p for p in g['params'] if p.requires_grad], lr=0.0, name=g['name']) for g in m.get_learnable_params()]
+    drv = StepDriver(m, FusedAdamW(gs, weight_decay=0.0))              # lr 0: the weights stay put, only the masks change
+    tok = m.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
+    tok = {k: v.cuda() for k, v in tok.items()}
+    g = GraphedStep(drv, images, tok, masks, labels, warmup=1)
+    losses = []
+    for _ in range(3):
+        L = g.step(images, tok, masks, labels)
+        losses.append(float(L['total_loss']))
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    assert len(set(losses)) == 3, losses                                # fresh masks on every replay
+    m.config.modality_dropout = 0.15; m.config.modality_dropout_warmup_epochs = 0; m.set_epoch(2)
+    with pytest.raises(ValueError):
+        GraphedStep(drv, images, tok, masks, labels, warmup=1)
