@@ -302,7 +302,8 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
-    // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip)
+    // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip; r01: a three-buffer ring
+    //  with counted vmcnt -- twice the bytes in flight per workgroup -- changed the step time by < 0.1 %: not kept)
     if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
     if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);
