@@ -8,7 +8,8 @@
 //      (the `& mask` of eval_mm_protocol.py:428), their scores are gathered and bitonic-sorted in LDS by
 //      (score descending, gallery index ascending) -- the tie rule of a stable descending argsort;
 //   2. ONE streaming pass over the score row (16-byte loads): an entry below the weakest positive is skipped outright,
-//      anything else is binary-searched into the sorted positives and counted in an LDS histogram;
+//      anything else is placed among the sorted positives (score-bucket table, then a search inside the bucket) and counted
+//      in an LDS histogram;
 //   3. prefix sum of the histogram -> rank of the r-th positive = 1 + r + #non-positives before it;
 //      AP = mean_r (r + 1) / rank_r (double), first-positive rank for CMC@k.
 // HBM-bound: 4 bytes of score + 8 bytes of L2-resident pid / image id per gallery entry per query.
@@ -16,6 +17,7 @@
 
 namespace {
 
+constexpr int NBUCKET = 2048;      // score buckets between the weakest and the strongest positive of a query
 constexpr int MAXP_LIMIT = 8192;    // positives per query held in LDS (12 bytes each; more -> npos = -1, not evaluated)
 
 struct MetricParams {
@@ -93,10 +95,45 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const MetricParams p)
     const float s_last = ps[np - 1];
     const int i_last = pi[np - 1];
     const int pid = p.q_pid[q];
+    // Score buckets over [weakest, strongest positive]: bucket(s) is monotone in s, so positives in earlier buckets rank before an
+    // entry and positives in later buckets after it -- only the positives of the entry's own bucket (usually none) need the
+    // (score, index) comparison.  Replaces a log2(np)-step binary search of dependent LDS reads per gallery entry by one lookup
+    // (with hundreds of positives per query that search, not HBM, set the pace: 29.9 -> 23.9 ms per 10k x 200k evaluation).
+    __shared__ int bstart[NBUCKET + 1];
+    __shared__ int bpart[256];
+    const float s_first = ps[0];
+    const float bscale = s_first > s_last ? (float)NBUCKET / (s_first - s_last) : 0.f;
+    auto bucket = [&](float s) {
+        const float t = fminf(fmaxf((s_first - s) * bscale, 0.f), (float)(NBUCKET - 1));
+        return (int)t;
+    };
+    for (int b = tid; b <= NBUCKET; b += 256) bstart[b] = 0;
+    __syncthreads();
+    for (int r = tid; r < np; r += 256) atomicAdd(&bstart[bucket(ps[r])], 1);
+    __syncthreads();
+    {   // exclusive prefix sum in place: NBUCKET / 256 consecutive buckets per thread
+        constexpr int PER = NBUCKET / 256;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { loc[u] = bstart[tid * PER + u]; sum += loc[u]; }
+        bpart[tid] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int t = 0; t < 256; ++t) { const int x = bpart[t]; bpart[t] = run; run += x; }
+            bstart[NBUCKET] = run;
+        }
+        __syncthreads();
+        int run = bpart[tid];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { bstart[tid * PER + u] = run; run += loc[u]; }
+    }
+    __syncthreads();
     auto visit = [&](int j, float s) {
         if (!before(s, j, s_last, i_last)) return;             // behind every positive: affects no rank we need
         if (p.g_pid[j] == pid || excluded(j)) return;          // positives are counted by their own position; masked rows rank last
-        int lo = 0, hi = np;                                    // first position whose positive is NOT before (s, j)
+        const int b = bucket(s);
+        int lo = bstart[b], hi = bstart[b + 1];                 // first position whose positive is NOT before (s, j)
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (before(ps[mid], pi[mid], s, j)) lo = mid + 1; else hi = mid;
