@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // Wave w owns key tile w (keys on the lane).  Per query tile: S = Q.K^T and dP = dO.V^T land as
 // [query rows (regs) x key columns (lanes)] and feed dV^T += dO^T.P and dK^T += Q^T.dS as B operands.
+// (160 VGPRs = 3 waves per SIMD, i.e. one 7-wave workgroup per CU.  r01 experiment: dV and dK in two sweeps over the query
+//  tiles -- 120 VGPRs, two workgroups per CU, S recomputed (20 instead of 16 MFMAs per tile pair) -- was 0.2 ms per step
+//  SLOWER: occupancy is not what holds this kernel back.)
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
