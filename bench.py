@@ -130,6 +130,7 @@ def retrieval_bench(dev):
     ref = torch.argsort((Q[:64] @ G.t()), dim=1, descending=True, stable=True)[:, :k]
     exact = bool((ref == idx[:64].long()).all())
     out = {'queries_per_s': Nq / t, 'ms': t * 1e3, 'Nq': Nq, 'Ng': Ng, 'D': D, 'k': k, 'tflops': 2.0 * Nq * Ng * D / t / 1e12,
+           'mfma_frac': 2.0 * Nq * Ng * D / t / 1e12 / PEAK_BF16_TFLOPS,
            'compulsory_bytes': (Nq + Ng) * D * 2 + Nq * k * 4, 'top10_equals_fp32_argsort_on_64_queries': exact}
     # the reference's one-query-at-a-time form (eval_mm_protocol.py:401-455): one pass over the fp32 gallery per call, HBM-bound
     q1 = Q[:1].contiguous()
@@ -144,6 +145,7 @@ def retrieval_bench(dev):
     us = e0.elapsed_time(e1) / 20 * 1e3
     out['single_query'] = {'us_per_call': us, 'queries_per_s': 1e6 / us, 'gallery_bytes_fp32': Ng * D * 4,
                            'gallery_GBps_end_to_end': Ng * D * 4 / (us * 1e-6) / 1e9, 'peak_GBps': PEAK_HBM_GBS,
+                           'hbm_frac_end_to_end': Ng * D * 4 / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                            'equals_batched_top10': bool(torch.equal(i1, idx[:1]))}
     # full MM-protocol metrics (mAP over the whole ranking + CMC) of the same 10k x 200k problem, gallery pids randint(0, 1000)
     from prcv2025reid_amd.evaluate import ProtocolEvaluator
