@@ -547,7 +547,7 @@ __device__ __forceinline__ int wave_select_lds(const float* sc, const int32_t* i
     return real < k ? real : k;
 }
 
-template <int DJ, int STREAM_ROWS>      // D = 256 * DJ
+template <int DJ, int STREAM_ROWS, int NQP>      // D = 256 * DJ; NQP = queries of the pass rounded up to 1, 2 or 4
 __global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng,
                                                           const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int nq,
                                                           int k, float* __restrict__ part_score, int32_t* __restrict__ part_idx) {
@@ -577,27 +577,61 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < DJ; ++j) gv[r][j] = __builtin_nontemporal_load((const f32x4*)(Gf + (size_t)row * D + lane * 4 + 256 * j));
         }
+        // All ROWS x nq partial dot products of this iteration are reduced over the wave TOGETHER: at each butterfly level a lane
+        // keeps one half of its values and sends the other half to its partner (8 + 4 + 2 + 1 exchanges for 16 values, then two plain
+        // levels), instead of six exchanges per value.  Every value is still summed over exactly the pairs of wave_sum's xor
+        // butterfly (32, 16, ..., 1), so the totals are bit-identical to select_kernel's; value v ends up in lanes [64/NV * v, ...).
+        // Used for up to 8 values (1-2 queries per pass); four queries reduce value by value.
+        {
+            constexpr int NV = STREAM_ROWS * NQP;
+            float v[NV];
 #pragma unroll
-        for (int r = 0; r < STREAM_ROWS; ++r) {
-            const int row = (int)(base + r);
-            if (row >= Ng) break;                                   // wave-uniform
-            const int eg = exg ? exg[row] : -2;
+            for (int r = 0; r < STREAM_ROWS; ++r)
 #pragma unroll
-            for (int q = 0; q < SQ; ++q) {
-                if (q >= nq) break;
-                float s = 0.f;
+                for (int q = 0; q < NQP; ++q) {
+                    float sdot = 0.f;
 #pragma unroll
-                for (int j = 0; j < DJ; ++j) s = dot4_acc(s, qv[q][j], gv[r][j]);      // the arithmetic of select_kernel, term for term
-                s = wave_sum(s);                                    // the same bits in every lane (commutative butterfly)
-                s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
-                if (eq[q] >= 0 && eg == eq[q]) s = -1e9f;
-                if (ranks_before(s, row, bar_s[q], bar_i[q])) {     // scalar branch
-                    if (lane == cnt[q]) { list[q].s = s; list[q].i = row; }
-                    if (++cnt[q] == 64) {
-                        lanelist_sort(list[q], 64, lane);
-                        cnt[q] = k;
-                        bar_s[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, list[q].s), k - 1));
-                        bar_i[q] = __builtin_amdgcn_readlane(list[q].i, k - 1);
+                    for (int j = 0; j < DJ; ++j) sdot = dot4_acc(sdot, qv[q][j], gv[r][j]);   // the arithmetic of select_kernel, term for term
+                    v[r * NQP + q] = sdot;
+                }
+            constexpr bool TOGETHER = NV <= 8;      // (16 values together cost 172 VGPRs -> two waves per SIMD: 206 us instead of 125)
+            if constexpr (TOGETHER) {
+                int dist = 32;
+#pragma unroll
+                for (int n = NV; n > 1; n >>= 1, dist >>= 1) {
+                    const bool hi = (lane & dist) != 0;
+#pragma unroll
+                    for (int i = 0; i < n / 2; ++i) {
+                        const float send = hi ? v[i] : v[i + n / 2];
+                        const float keep = hi ? v[i + n / 2] : v[i];
+                        v[i] = keep + __shfl_xor(send, dist, 64);
+                    }
+                }
+#pragma unroll
+                for (int dd = 32 / NV; dd >= 1; dd >>= 1) v[0] += __shfl_xor(v[0], dd, 64);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+            }
+#pragma unroll
+            for (int r = 0; r < STREAM_ROWS; ++r) {
+                const int row = (int)(base + r);
+                if (row >= Ng) break;                               // wave-uniform
+                const int eg = exg ? exg[row] : -2;
+#pragma unroll
+                for (int q = 0; q < NQP; ++q) {
+                    if (q >= nq) break;
+                    float s = TOGETHER ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), (64 / NV) * (r * NQP + q)))
+                                       : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[r * NQP + q])));
+                    if (eq[q] >= 0 && eg == eq[q]) s = -1e9f;
+                    if (ranks_before(s, row, bar_s[q], bar_i[q])) {     // scalar branch
+                        if (lane == cnt[q]) { list[q].s = s; list[q].i = row; }
+                        if (++cnt[q] == 64) {
+                            lanelist_sort(list[q], 64, lane);
+                            cnt[q] = k;
+                            bar_s[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, list[q].s), k - 1));
+                            bar_i[q] = __builtin_amdgcn_readlane(list[q].i, k - 1);
+                        }
                     }
                 }
             }
@@ -702,7 +736,8 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
         const int32_t* eq = exclude_q ? exclude_q + q0 : nullptr;
         // gallery rows per wave and iteration (the loads of all rows are issued before the first dot): 4 rows = 8 KiB in flight per wave at D = 512
         static const int rows_env = [] { const char* e = getenv("REID_STREAM_ROWS"); return e ? atoi(e) : 0; }();
-#define REID_STREAM_LAUNCH(DJ, R) hipLaunchKernelGGL((stream_topk_kernel<DJ, R>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
+#define REID_STREAM_LAUNCH1(DJ, R, P) hipLaunchKernelGGL((stream_topk_kernel<DJ, R, P>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
+#define REID_STREAM_LAUNCH(DJ, R) do { if (nq == 1) REID_STREAM_LAUNCH1(DJ, R, 1); else if (nq == 2) REID_STREAM_LAUNCH1(DJ, R, 2); else REID_STREAM_LAUNCH1(DJ, R, 4); } while (0)
         switch (D / 256) {
             case 1: REID_STREAM_LAUNCH(1, 4); break;
             case 2: if (rows_env == 2) REID_STREAM_LAUNCH(2, 2); else if (rows_env == 8) REID_STREAM_LAUNCH(2, 8); else REID_STREAM_LAUNCH(2, 4); break;
@@ -710,6 +745,7 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
             default: REID_STREAM_LAUNCH(4, 2); break;
         }
 #undef REID_STREAM_LAUNCH
+#undef REID_STREAM_LAUNCH1
         REID_CHECK_LAUNCH("reid_cosine_topk_stream(scan)");
         hipLaunchKernelGGL(stream_merge_kernel, dim3(nq), dim3(256), (size_t)groups * k * 8, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
                            out_score + (size_t)q0 * k);
