@@ -61,6 +61,11 @@ class GalleryIndex:
         idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
         sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
         ops.cosine_topk(Qb, self.Gb, Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
+        if Nq * Ng <= (1 << 26):       # small problems: run the exact pass unconditionally -- its kernels return at once for queries
+            # that are not flagged -- instead of reading the flags back (a host sync costs more than two empty launches here)
+            scratch = torch.empty(Nq * Ng, dtype=torch.float32, device=Qf.device)
+            ops.cosine_topk_exact(Qf, self.Gf, k, scratch, idx, sc, exclude_q=exq, exclude_g=exg)
+            return idx, sc
         flagged = (idx[:, 0] == -2)
         if bool(flagged.any()):        # candidate-list overflow (thousands of near-ties): exact fp32 pass for those queries
             rows = flagged.nonzero().flatten()

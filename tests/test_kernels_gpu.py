@@ -470,22 +470,23 @@ def test_small_head_kernels(ops):
     assert H.NanToNumFn.apply(t).tolist() == [1.0, 0.0, 1e4, -1e4]
 
 
-def test_cosine_topk_overflow_fallback_is_exact(ops):
-    """Thousands of near-duplicates overflow the candidate list: the query is flagged and the exact fp32 pass resolves it."""
+@pytest.mark.parametrize('n_other', [7, 2300])
+def test_cosine_topk_overflow_fallback_is_exact(ops, n_other):
+    """Thousands of near-duplicates overflow the candidate list: the query is flagged and the exact fp32 pass resolves it
+    (small problems run that pass without reading the flags back; large ones gather the flagged queries on the host side)."""
     from prcv2025reid_amd.retrieval import GalleryIndex
     g = torch.Generator(device='cuda').manual_seed(3)
     D, Ng, k = 512, 30000, 10
     base = torch.nn.functional.normalize(torch.randn(1, D, device='cuda', generator=g), dim=1)
     G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
     G[10000:20000] = torch.nn.functional.normalize(base + 1e-3 * torch.randn(10000, D, device='cuda', generator=g), dim=1)
-    Q = torch.cat([base, torch.nn.functional.normalize(torch.randn(7, D, device='cuda', generator=g), dim=1)])
+    Q = torch.cat([base, torch.nn.functional.normalize(torch.randn(n_other, D, device='cuda', generator=g), dim=1)])
     idx, sc = GalleryIndex(G, normalized=True).topk(Q, k=k, normalized=True)
     ref = torch.argsort((Q.double() @ G.double().t()).float(), dim=1, descending=True, stable=True)[:, :k]
     sim = Q.double() @ G.double().t()
-    for qi in range(Q.shape[0]):
-        for r in range(k):
-            a, b = int(ref[qi, r]), int(idx[qi, r])
-            assert a == b or abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
+    for qi, r in (ref != idx.long()).nonzero().tolist():
+        a, b = int(ref[qi, r]), int(idx[qi, r])
+        assert abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
 
 
 def test_sharded_gallery_single_process(ops):
