@@ -2,24 +2,34 @@
 """Benchmark of the hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N = 1 runs in this process.  N > 1 with no WORLD_SIZE in the environment: this process stays CPU-only, SPAWNS N rank processes
+(one per GPU, torch.distributed backend nccl = RCCL over xGMI, rendezvous on 127.0.0.1) and relays rank 0's JSON line; when the
+driver launches the ranks itself (python -m torch.distributed.run ... bench.py --gpus N) WORLD_SIZE is set and must equal N.
 
 A "step" = one pass of the training hot path over one synthetic P x K batch per GPU:
 zero_grad -> forward (4 vision modalities + text through the HIP executor) -> CE + SDM losses ->
 backward (hand-written HIP backward, LoRA/bn_neck/null-token gradients = the reference's default
 trainable set, train.py:1418-1425) -> gradient all-reduce (N > 1) -> AdamW step.
-Workload at every N: BASELINE.json configs[1] per GPU (P=16, K=4, LoRA r=8, masks all-on, ViT-B/16 + CLIP
-text random-init, 400 identities), inputs resident in HBM; weak scaling.
+Workload: N = 1: BASELINE.json configs[1] (P=16, K=4, LoRA r=8, masks all-on, ViT-B/16 + CLIP text random-init, 400
+identities).  N > 1: configs[2] (P=32, K=4 PER GPU, same model; weak scaling), and the line also carries the single-GPU
+value of that same per-GPU workload measured on rank 0 alone (`n1_same_workload`).  Inputs are resident in HBM.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mer_gemm_kernel<256,256,2,4> + <128,256,2,4>, bf16 MFMA): algorithmic FLOPs of every launch in
+  roofline      -- dominant kernel (mer_gemm_kernel<128,128,2,2>, bf16 MFMA): algorithmic FLOPs of every launch in
                    the timed region / its duration measured with HIP events on the launch stream
-  cpu_baseline  -- the CPU oracle (oracle/reid_oracle.py, kind "port") timed on this host on a bounded sample
+  flavors       -- step time of BOTH 16-bit operand flavors (bf16 = headline, f16) on the same workload
+  parity        -- per flavor, HIP vs the CPU oracle on the full-size batch of this workload (regularisers off): per-modality
+                   features, bn_features / 8, the three losses -- so the record shows which flavor meets 1e-3 and its speed
+  cpu_baseline  -- the CPU oracle (oracle/reid_oracle.py, kind "port") timed on this host on a bounded sample, plus the two
+                   CPU retrieval baselines of SURVEY 8(d)
   retrieval     -- eval queries/s of the fused cosine top-10 on 10k x 200k x 512 (BASELINE.json configs[3])
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +52,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--P', type=int, default=16)
+    ap.add_argument('--P', type=int, default=None, help='identities per GPU (default: 16 at N=1 = BASELINE config 2, 32 at N>1 = config 3)')
     ap.add_argument('--K', type=int, default=4)
     ap.add_argument('--rank', type=int, default=8, help='LoRA rank')
     ap.add_argument('--mask-drop', type=float, default=0.0)
@@ -53,14 +63,19 @@ def parse():
     ap.add_argument('--graph', default='off', choices=['auto', 'on', 'off'],
                     help='replay the step as a HIP graph (single process only; measured ~1 ms/step SLOWER than eager launches on MI355X, r01)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL); gloo only for rehearsals')
-    ap.add_argument('--compute-dtype', default=None, choices=[None, 'bf16', 'f16'])
+    ap.add_argument('--compute-dtype', default=None, choices=[None, 'bf16', 'f16'], help='headline flavor (default bf16)')
+    ap.add_argument('--no-second-flavor', action='store_true', help='skip the step-time leg of the other 16-bit flavor')
+    ap.add_argument('--no-parity', action='store_true', help='skip the in-run full-size parity check against the CPU oracle')
     return ap.parse_args()
+
+
+PMC_FILE = 'r02_pmc_traffic.json'
 
 
 def pmc_traffic(*kernels):
     """Launch-weighted HBM bytes per launch of `kernels` from the committed PMC summary (collected with separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide prescribes)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', PMC_FILE)
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -105,9 +120,37 @@ def cpu_baseline():
         if it > 0:
             times.append(time.perf_counter() - t0)
     t = sum(times) / len(times)
-    return {'value': 8.0 / t, 'unit': 'instances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle fp32, P=4,K=2 (8 instances), LoRA r=4, fwd+loss+bwd, 1 warm-up + 3 timed steps',
-            'seconds_per_step': t}
+    res = {'value': 8.0 / t, 'unit': 'instances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': 'oracle fp32, P=4,K=2 (8 instances), LoRA r=4, fwd+loss+bwd, 1 warm-up + 3 timed steps',
+           'seconds_per_step': t}
+    res['retrieval'] = cpu_retrieval_baselines(cores)
+    return res
+
+
+def cpu_retrieval_baselines(cores):
+    """The two CPU retrieval baselines of SURVEY 8(d) on the 200k x 512 gallery (oracle functions, host cores):
+    (a) chunked fp32 Q @ G.T + topk(10) over 1 000 queries; (b) the reference's form -- one query at a time, GEMV + FULL
+    argsort of the 200k scores (tools/eval_mm_protocol.py:401-423, train.py:450-479) -- over 100 queries."""
+    from oracle import reid_oracle as O
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(2)
+    Ng, D = 200000, 512
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, generator=g), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(1000, D, generator=g), dim=1)
+    log('cpu_baseline: chunked fp32 GEMM + top-10, 1000 queries x 200k')
+    O.cosine_sim(Q[:100], G).topk(10, dim=1)
+    t0 = time.perf_counter()
+    O.cosine_sim(Q, G).topk(10, dim=1)
+    ta = time.perf_counter() - t0
+    log('cpu_baseline: reference-style per-query GEMV + full argsort, 100 queries x 200k')
+    O.rank_full(O.cosine_sim(Q[:1], G).squeeze(0))
+    t0 = time.perf_counter()
+    for i in range(100):
+        O.rank_full(O.cosine_sim(Q[i:i + 1], G).squeeze(0))
+    tb = time.perf_counter() - t0
+    return {'chunked_gemm_topk10': {'queries_per_s': 1000 / ta, 'sample': '1000 queries x 200k x 512 fp32 matmul + topk(10)', 'cores': cores},
+            'per_query_gemv_full_argsort': {'queries_per_s': 100 / tb, 'sample': '100 queries x 200k x 512, one GEMV + full stable argsort each '
+                                            '(eval_mm_protocol.py:401-423)', 'cores': cores}}
 
 
 def retrieval_bench(dev):
@@ -197,46 +240,47 @@ def encode_bench(model, dev, arch):
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    import torch.distributed as dist
-    ndev = torch.cuda.device_count()
-    local = local % max(1, ndev)                   # (rehearsal: several ranks may share one GPU under gloo)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
-    from prcv2025reid_amd import ops
+def spawn_ranks(args):
+    """N > 1 and no WORLD_SIZE: this (parent) process never touches a GPU; it starts N fresh rank processes and relays rank 0's line."""
+    n = args.gpus
+    ndev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU on this image)
+    if args.backend == 'nccl' and ndev < n:
+        raise SystemExit(f'bench.py --gpus {n}: only {ndev} GPU(s) visible (use --backend gloo to rehearse several ranks on one GPU)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    line = [ln for ln in (out or '').splitlines() if ln.startswith('{')]
+    if any(rcs) or not line:
+        sys.stderr.write(out or '')
+        raise SystemExit(f'bench.py: rank exit codes {rcs}')
+    print(line[-1], flush=True)
+
+
+def build_model(local, rank_lora, flavor, C, regularisers=True):
     from prcv2025reid_amd.config import TrainingConfig
     from prcv2025reid_amd.model import CLIPBasedMultiModalReIDModel, apply_reference_freeze
-    from prcv2025reid_amd.parallel import DataParallel
-    from prcv2025reid_amd.synthetic import synthetic_batch
-
-    C = 400
-    cfg = TrainingConfig(device=f'cuda:{local}', mer_lora_rank=args.rank, contrastive_weight=0.1, seed=0,
-                         compute_dtype=args.compute_dtype)
+    kw = {} if regularisers else dict(drop_path=0.0, modality_dropout=0.0, dropout_rate=0.0, fusion_dropout=0.0, sdm_dropout=0.0)
+    # init='seeded': every tensor random (lora_B included), so no path of the step is vacuous
+    cfg = TrainingConfig(device=f'cuda:{local}', mer_lora_rank=rank_lora, contrastive_weight=0.1, seed=0, compute_dtype=flavor,
+                         init='seeded', **kw)
     model = CLIPBasedMultiModalReIDModel(cfg)
     model.set_num_classes(C)
     apply_reference_freeze(model)
     model.set_epoch(2)
     model.train()
-    dp = DataParallel(model)
-    P, K = args.P, args.K
-    B = P * K
-    batch = synthetic_batch(P, K, model.arch, seed=1000 + rank, mask_drop=args.mask_drop, num_classes=C, label_offset=rank * P)
-    images = {m: t.to(dev) for m, t in batch['images'].items()}
-    masks = batch['modality_mask']                      # host tensors, as the reference's collate produces them
-    tok = model.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
-    tokens = {k: v.to(dev) for k, v in tok.items()}     # pre-tokenised, resident in HBM
-    labels = batch['person_id'].to(dev)
-    groups = [dict(params=[p for p in g['params'] if p.requires_grad], lr=g['lr'], name=g['name'])
-              for g in model.get_learnable_params()]
+    return model
+
+
+def make_stepper(model, dp, args, images, tokens, masks, labels, world):
+    groups = [dict(params=[p for p in g['params'] if p.requires_grad], lr=g['lr'], name=g['name']) for g in model.get_learnable_params()]
     groups = [g for g in groups if g['params']]
     graphed = False
     if args.optimizer == 'fused':
@@ -273,26 +317,125 @@ def main():
             opt.step()
             return L
         eager_step = step
+    return step, eager_step, graphed
 
-    log(f'model built, {args.warmup} warm-up steps')
-    for _ in range(args.warmup):
+
+def timed(step, steps, warmup, world, dev):
+    import torch.distributed as dist
+    for _ in range(warmup):
         L = step()
-    log(f'timing {args.steps} steps')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         L = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed, L
+
+
+def parity_check(local, rank_lora, C, P, K, flavors):
+    """HIP (each flavor) vs the CPU oracle on the FULL-SIZE batch of the benchmarked workload, training forward with the random
+    regularisers off (the oracle is deterministic): unit-normalised per-modality features and bn_features / 8, the three losses."""
+    from oracle import reid_oracle as O
+    from prcv2025reid_amd.synthetic import synthetic_batch
+    from prcv2025reid_amd.weights import seeded_state
+    res = {'oracle': 'oracle/reid_oracle.py (fp32 CPU restatement pinned to the reference fixtures), train-mode forward + losses, '
+                     f'regularisers off, same seeded weights and batch (P={P},K={K}, r={rank_lora}, masks all-on)', 'tolerance_north_star': 1e-3}
+    ref = Lr = None
+    for fl in flavors:
+        model = build_model(local, rank_lora, fl, C, regularisers=False)
+        arch = model.arch
+        if ref is None:
+            state = seeded_state(arch, C, 0)
+            batch = synthetic_batch(P, K, arch, seed=1000, num_classes=C)
+            tok = model.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
+            cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16))
+            torch.set_num_threads(cores)
+            log(f'parity: oracle forward on {P * K} instances ({cores} threads)')
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                ref = O.forward(state, arch, batch['images'], tok, batch['modality_mask'], True)
+                Lr = O.compute_loss(ref, batch['person_id'], contrastive_weight=0.1, tau=0.2)
+            res['oracle_seconds'] = time.perf_counter() - t0
+        model.load_state_dict(state)
+        with torch.no_grad():
+            out = model(images={m: t.to(f'cuda:{local}') for m, t in batch['images'].items()},
+                        texts={k: v.to(f'cuda:{local}') for k, v in tok.items()}, modality_masks=batch['modality_mask'])
+            L = model.compute_loss(out, batch['person_id'].to(f'cuda:{local}'))
+        emb = float((out['bn_features'].cpu() / 8 - ref['bn_features'] / 8).abs().max())
+        per = {}
+        for m in ref['raw_modality_features']:
+            a = torch.nn.functional.normalize(out['raw_modality_features'][m].cpu(), dim=1)
+            b = torch.nn.functional.normalize(ref['raw_modality_features'][m], dim=1)
+            per[m] = float((a - b).abs().max())
+        dl = {k: abs(float(L[k]) - float(Lr[k])) for k in ('total_loss', 'ce_loss', 'sdm_loss')}
+        worst = max([emb] + list(per.values()) + list(dl.values()))
+        res[fl] = {'bn_features_unit_maxabs': emb, 'per_modality_unit_maxabs': per, 'loss_abs': dl,
+                   'losses_hip': {k: float(L[k]) for k in dl}, 'losses_oracle': {k: float(Lr[k]) for k in dl},
+                   'worst': worst, 'meets_1e-3': bool(worst <= 1e-3)}
+        log(f'parity[{fl}]: bn_features/8 {emb:.2e}, per-modality {max(per.values()):.2e}, losses {max(dl.values()):.2e}')
+        del model
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args)
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}) or drop WORLD_SIZE')
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)                   # (rehearsal: several ranks may share one GPU under gloo)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    from prcv2025reid_amd import ops
+    from prcv2025reid_amd.parallel import DataParallel
+    from prcv2025reid_amd.synthetic import synthetic_batch
+
+    C = 400
+    P = args.P if args.P is not None else (16 if world == 1 else 32)        # BASELINE configs[1] / configs[2]
+    K = args.K
+    B = P * K
+    head = args.compute_dtype or 'bf16'
+    other = 'f16' if head == 'bf16' else 'bf16'
+    model = build_model(local, args.rank, head, C)
+    dp = DataParallel(model)
+    batch = synthetic_batch(P, K, model.arch, seed=1000 + rank, mask_drop=args.mask_drop, num_classes=C, label_offset=rank * P)
+    images = {m: t.to(dev) for m, t in batch['images'].items()}
+    masks = batch['modality_mask']                      # host tensors, as the reference's collate produces them
+    tok = model.tokenizer(batch['texts'], return_tensors='pt', padding=True, truncation=True, max_length=77)
+    tokens = {k: v.to(dev) for k, v in tok.items()}     # pre-tokenised, resident in HBM
+    labels = batch['person_id'].to(dev)
+    step, eager_step, graphed = make_stepper(model, dp, args, images, tokens, masks, labels, world)
+
+    log(f'[{head}] model built, {args.warmup} warm-up + {args.steps} timed steps (P={P},K={K} per GPU, world {world})')
+    elapsed, L = timed(step, args.steps, args.warmup, world, dev)
     # Kernel-duration pass for the roofline: the SAME K steps again, now with a HIP event pair around every launch of the
     # dominant kernels on the launch stream.  It is a second pass because timing events are not free here: each record is a
     # system-scope fence (L2 write-back), which slowed the step by 15-25 % when taken inside the throughput region.
     prof, ln_prof = [], []
+    ms_with_events = None
     if not args.no_kernel_events:
         ops.gemm_profile_begin(); ops.ln_profile_begin()
         te = time.perf_counter()
@@ -301,51 +444,77 @@ def main():
         torch.cuda.synchronize()
         ms_with_events = (time.perf_counter() - te) / args.steps * 1e3
         prof = ops.gemm_profile_end(); ln_prof = ops.ln_profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
     loss = float(L['total_loss'].detach())
+    loss_spread = params_spread = 0.0
     if world > 1:                                  # every rank evaluates the same global loss (parallel.py): check it
         lt = torch.tensor([loss, -loss], device=dev, dtype=torch.float64)
         dist.all_reduce(lt, op=dist.ReduceOp.MAX)
         loss_spread = abs(float(lt[0]) + float(lt[1]))   # max over ranks - min over ranks; reported, and loud when it is not rounding
         if loss_spread > 1e-5 * max(1.0, abs(loss)):
             log(f'WARNING: ranks disagree on the global loss by {loss_spread:.3e} (loss {loss:.6f})')
-    else:
-        loss_spread = 0.0
+        params_spread = dp.params_in_sync()              # replicas must stay bit-identical (head gradients are averaged too)
+    value = world * B * args.steps / elapsed
+    res = {
+        'metric': 'multimodal instances/sec (PxK, 5-modality) at 1/2/4/8 GPU; eval queries/sec',
+        'value': value, 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': model.compute_dtype, 'data': 'synthetic',
+        'config': {'workload': f'P={P},K={K} per GPU, vis/nir/sk/cp 224x224 + text (T<=77), CLIP ViT-B/16 + text tower '
+                               f'random-init, MER-LoRA r={args.rank}, masks {"all-on" if args.mask_drop == 0 else args.mask_drop}, '
+                               f'{C} ids, SDM+CE, fwd+bwd+grad sanitise/clip+AdamW (reference default trainable set)',
+                   'baseline_config': 'configs[1] 1xMI355X P=16,K=4' if (world == 1 and P == 16) else
+                                      ('configs[2] DP P=32,K=4 per GPU' if P == 32 else 'custom'),
+                   'P': P, 'K': K, 'global_batch': world * B, 'lora_rank': args.rank, 'parallelism': f'dp{world}'},
+        'model_tflops_per_gpu': value / world * FLOP_PER_INSTANCE / 1e12,
+        'mfma_frac_whole_step': value / world * FLOP_PER_INSTANCE / 1e12 / PEAK_BF16_TFLOPS,
+        'final_loss': loss, 'loss_spread_over_ranks': loss_spread, 'params_spread_over_ranks': params_spread,
+        'rccl_world': (world if (world > 1 and args.backend == 'nccl') else 0), 'backend': args.backend if world > 1 else None,
+        'hip_graph': graphed,
+    }
+    if prof:
+        fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        ach = fl / (ms * 1e-3) / 1e12
+        res['roofline'] = {'kernel': 'mer_gemm_kernel<128,128,2,2>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<128, 128, 2, 2>'),
+                           'traffic_note': f'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/{PMC_FILE}); null if not collected',
+                           'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
+                           'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
+                           'flops_per_launch_avg': fl / len(prof)}
+    if ln_prof:
+        nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
+        gbs = nb / (ms * 1e-3) / 1e9
+        res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                               'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true, false>') or pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
+                               'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
+    res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
+    if world > 1:
+        # single-GPU value of the SAME per-GPU workload, rank 0 alone (the others wait): what the N-GPU value is to be divided by
+        dist.barrier()
+        if rank == 0:
+            s1, _, _ = make_stepper(model, DataParallel(model, enabled=False), args, images, tokens, masks, labels, 1)
+            e1, _ = timed(s1, args.steps, 1, 1, dev)
+            res['n1_same_workload'] = {'value': B * args.steps / e1, 'ms_per_step': e1 / args.steps * 1e3, 'unit': 'instances/s',
+                                       'what': f'P={P},K={K} on one GPU (rank 0 alone, no collectives), same process and model'}
+            res['scaling_vs_n1_same_workload'] = value / res['n1_same_workload']['value']
+        dist.barrier()
+    del step, eager_step
+    if world == 1 and not args.no_second_flavor:
+        # the other 16-bit flavor on the same workload, same K / W (f16 meets north_star's 1e-3 as written; see `parity`)
+        del dp, model
+        torch.cuda.empty_cache()
+        m2 = build_model(local, args.rank, other, C)
+        dp2 = DataParallel(m2)
+        s2, _, _ = make_stepper(m2, dp2, args, images, tokens, masks, labels, 1)
+        log(f'[{other}] second flavor: {args.warmup} warm-up + {args.steps} timed steps')
+        e2, L2 = timed(s2, args.steps, args.warmup, 1, dev)
+        res['flavors'][other] = {'ms_per_step': e2 / args.steps * 1e3, 'value': B * args.steps / e2, 'final_loss': float(L2['total_loss'].detach())}
+        del s2, dp2
+        model = m2
     if rank == 0:
-        value = world * B * args.steps / elapsed
-        res = {
-            'metric': 'multimodal instances/sec (PxK, 5-modality) at 1/2/4/8 GPU; eval queries/sec',
-            'value': value, 'unit': 'instances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': model.compute_dtype, 'data': 'synthetic',
-            'config': {'workload': f'P={P},K={K} per GPU, vis/nir/sk/cp 224x224 + text (T<=77), CLIP ViT-B/16 + text tower '
-                                   f'random-init, MER-LoRA r={args.rank}, masks {"all-on" if args.mask_drop == 0 else args.mask_drop}, '
-                                   f'{C} ids, SDM+CE, fwd+bwd+grad sanitise/clip+AdamW (reference default trainable set)',
-                       'P': P, 'K': K, 'global_batch': world * B, 'lora_rank': args.rank, 'parallelism': f'dp{world}'},
-            'model_tflops_per_gpu': value / world * FLOP_PER_INSTANCE / 1e12,
-            'mfma_frac_whole_step': value / world * FLOP_PER_INSTANCE / 1e12 / PEAK_BF16_TFLOPS,
-            'final_loss': loss, 'loss_spread_over_ranks': loss_spread, 'hip_graph': graphed,
-        }
-        if prof:
-            fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
-            ach = fl / (ms * 1e-3) / 1e12
-            res['roofline'] = {'kernel': 'mer_gemm_kernel<128,128,2,2>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<128, 128, 2, 2>'),
-                               'traffic_note': 'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/r01_pmc_traffic.md); null if not collected',
-                               'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
-                               'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
-                               'flops_per_launch_avg': fl / len(prof)}
-        if ln_prof:
-            nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
-            gbs = nb / (ms * 1e-3) / 1e9
-            res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true, false>') or pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
-                                   'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
+        if world == 1 and not args.no_parity:
+            torch.cuda.empty_cache()
+            res['parity'] = parity_check(local, args.rank, C, P, K, [head, other])
         if world == 1 and not args.no_retrieval:
-            del opt
             torch.cuda.empty_cache()
             log(f'train: {value:.1f} instances/s; retrieval bench')
             res['retrieval'] = retrieval_bench(dev)

@@ -51,6 +51,10 @@ int reid_version(void);
 int reid_flavor(void);
 /* Checks that device `dev` is gfx950 (MI355X).  */
 int reid_check_device(int dev);
+/* Experiment knobs (tools/ and the A/B harnesses only; the product path never calls this): sets the cached value of
+ * knob `name` ("GEMM_TILE", "GEMM_DBG", "GEMM_PERSIST", "GEMM_STAGGER", ... = the REID_<name> environment variables,
+ * which are read ONCE per process); value -1 restores "not set" (the built-in default). */
+int reid_set_knob(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * MER GEMM:  C = epilogue( A . B^T  +  A2 . B2^T + bias )      bf16 MFMA, fp32 accumulate

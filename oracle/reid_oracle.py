@@ -21,7 +21,8 @@ The reference has no test-suite of its own for this path.
 
 All stochastic regularisers of the reference (DropPath clip_backbone.py:126-142,
 dropouts model.py:31-36,43,92-106,200, batch-level modality dropout
-model.py:435-473) are OFF here: parity is defined with them disabled.
+model.py:435-473) are OFF here unless their random outcome is passed in explicitly
+(``drop_scales``, ``moddrop_keep``): parity is defined with them disabled or fixed.
 """
 import math
 from typing import Dict, List, Optional, Sequence
@@ -259,8 +260,14 @@ def bn_neck(x, state, training: bool):
 
 # --------------------------------------------------------------------------- A8 forward
 def forward(state, arch, images: Optional[Dict[str, torch.Tensor]], tokens: Optional[Dict[str, torch.Tensor]],
-            modality_masks: Optional[Dict[str, torch.Tensor]], training: bool):
+            modality_masks: Optional[Dict[str, torch.Tensor]], training: bool,
+            moddrop_keep: Optional[Dict[str, bool]] = None, min_modalities: int = 1):
     """CLIPBasedMultiModalReIDModel.forward, model.py:321-510 (regularisers off).
+
+    ``moddrop_keep`` = {modality: keep?}: the outcome of the batch-level modality-dropout draws of model.py:449-453
+    (``torch.rand(1).item() > p`` per non-'vis' modality), given explicitly so a test can fix them; None = no dropout.
+    Restated from model.py:435-473: dropped modalities leave BOTH the fused list and ``feature_masks``; the draw is
+    cancelled if fewer than ``min_modalities`` would remain or a sample would be left without any valid modality.
 
     ``tokens`` = {'input_ids','attention_mask'} (the reference tokenises List[str]
     on the host, clip_backbone.py:297-303).  Quirk kept: with no mask for a vision
@@ -304,6 +311,13 @@ def forward(state, arch, images: Optional[Dict[str, torch.Tensor]], tokens: Opti
         sem['text'] = sdm_module(tf, state) if training else tf
     if not sem:
         raise ValueError('no modality given')
+    if training and moddrop_keep is not None and len(sem) > min_modalities:
+        kept = [m for m in sem if m == 'vis' or moddrop_keep.get(m, True)]
+        if len(kept) >= min_modalities:
+            alive = torch.stack([fmask[m] for m in kept], dim=1).bool().any(dim=1)
+            if bool(alive.all()):
+                sem = {m: sem[m] for m in kept}
+                fmask = {m: fmask[m] for m in kept}
     flist = list(sem.values()); mlist = [fmask[m] for m in sem]
     fused = flist[0] if len(flist) == 1 else feature_fusion(flist, mlist, state, arch['fusion_num_heads'])
     out = {'features': fused, 'raw_modality_features': raw, 'modality_features': sem, 'feature_masks': fmask}

@@ -32,7 +32,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU = range(7)
 
 EXPORTS = [
-    'reid_last_error', 'reid_version', 'reid_flavor', 'reid_check_device', 'reid_mer_gemm', 'reid_gemm_tn',
+    'reid_last_error', 'reid_version', 'reid_flavor', 'reid_check_device', 'reid_set_knob', 'reid_mer_gemm', 'reid_gemm_tn',
     'reid_layernorm_fwd', 'reid_layernorm_bwd', 'reid_patch_im2col', 'reid_cls_rows',
     'reid_attn_fwd', 'reid_attn_bwd', 'reid_cast_f32_bf16', 'reid_cast_bf16_f32', 'reid_gather_rows_f32',
     'reid_bnneck_stats', 'reid_bnneck_fwd', 'reid_bnneck_bwd_p1', 'reid_bnneck_bwd_p2',

@@ -190,11 +190,19 @@ def clip_to_reference_state(hf: Dict[str, torch.Tensor], arch: dict) -> 'Ordered
     return out
 
 
-def load_clip_pretrained(model, local_dir: str):
-    """Initialise ``model`` from a local HF CLIP directory the way the reference initialises itself from the hub.
-    Tensors CLIP does not provide (LoRA adapters, fusion, SDM module, BN-neck, null tokens, patch-embed biases) keep their
-    current values."""
+def load_clip_pretrained(model, local_dir: str, noise_seed: Optional[int] = None):
+    """Initialise ``model`` from a local HF CLIP directory the way the reference initialises itself from the hub
+    (clip_backbone.py:166-252): CLIP tensors are copied in; the non-'vis' patch convolutions additionally get the reference's
+    N(0, 0.02^2) weight noise (patch_embeds.py:150-167; seeded here by ``noise_seed``, default config.seed).  Tensors CLIP
+    does not provide keep their current values -- for a freshly constructed model (``config.init = 'reference'``) those are the
+    reference's own construction values: lora_B = 0 / lora_A kaiming-uniform (initial low-rank update exactly 0), xavier SDM
+    module, default fusion block, BN-neck (1, 0), null tokens N(0, 0.02^2)."""
     ref = clip_to_reference_state(_read_hf_weights(local_dir), model.arch)
+    seed = int(getattr(model.config, 'seed', 42) if noise_seed is None else noise_seed)
+    for m in ('nir', 'sk', 'cp'):
+        k = f'{_CE}patch_embeds.{m}.proj.weight'
+        g = torch.Generator().manual_seed(seed * 1000003 + sum(map(ord, m)))
+        ref[k] = ref[k] + torch.randn(ref[k].shape, generator=g) * 0.02
     res = model.load_state_dict(ref, strict=False)
     model._dead_state = {k: v for k, v in ref.items() if is_dead_key(k)}
     return res

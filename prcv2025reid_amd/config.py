@@ -139,6 +139,10 @@ class TrainingConfig:
     # 16-bit MFMA operand format of the HIP path: 'bf16' (8 significant bits) or 'f16' (11 bits, backward pass
     # runs loss-scaled).  None -> environment REID_T16, default 'bf16'.  See DESIGN.md "Precision".
     compute_dtype: Optional[str] = None
+    # Initial values of a freshly constructed model: 'reference' = the reference's construction semantics (lora_B = 0, lora_A
+    # kaiming-uniform, xavier SDM module, CLIP-derived patch convolutions + noise; seeded stand-ins where the reference downloads
+    # CLIP), 'seeded' = every tensor random (prcv2025reid_amd.weights.seeded_state: what the parity fixtures and the bench use).
+    init: str = 'reference'
 
     # ---- backbone architecture (taken from the HF checkpoint in the reference) ----
     vision_layers: int = 12

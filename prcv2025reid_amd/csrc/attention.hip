@@ -540,7 +540,7 @@ extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     if (rc) return rc;
     REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
     AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0};
-    { const char* e = getenv("REID_ATTN_DBG"); if (e) p.dbg = atoi(e); }
+    if (reid_knob(KNOB_ATTN_DBG) > 0) p.dbg = reid_knob(KNOB_ATTN_DBG);
     DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
 }
 

@@ -34,7 +34,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_m;  // row tiles per L2 group of the tile order (gemm_core.h tile_coords)
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
-    int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue
+    int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
 };
 
 using namespace gemmcore;
@@ -230,8 +230,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
 
     f32x4 acc[C::TN][C::TM];
     init_acc<C::TM, C::TN>(p, acc, n0 + wn * (BN / WN), lane);
-    mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
-                             p.perm_b != 0);
+    if (p.dbg != 4)
+        mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
+                                 p.perm_b != 0);
 
     // ------------------------------------------------------------------ epilogue (registers -> global, no LDS)
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -298,7 +299,7 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     // L2 group height of the tile order: 16 row tiles when the weight panel set is wide and K short (q|k|v, fc1: the whole
     // [N, K] weight no longer fits one XCD's L2 next to 8 activation tiles and was re-streamed per group; r01 sweep 4..64)
     p.group_m = (p.K + p.K2 <= 1024 && p.N >= 1536) ? 16 : 8;
-    { const char* e_g = getenv("REID_GEMM_GROUPM"); if (e_g && atoi(e_g) > 0) p.group_m = atoi(e_g); }
+    if (reid_knob(KNOB_GEMM_GROUPM) > 0) p.group_m = reid_knob(KNOB_GEMM_GROUPM);
     p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
@@ -307,11 +308,9 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
     if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);
-    // experiment knobs (read per call so a benchmark can A/B tiles inside one process)
-    const char* e_tile = getenv("REID_GEMM_TILE");
-    const char* e_dbg = getenv("REID_GEMM_DBG");
-    const int tile = e_tile ? atoi(e_tile) : 0;
-    p.dbg = e_dbg ? atoi(e_dbg) : 0;
+    // experiment knobs (cached table, common.h; a benchmark A/Bs tiles inside one process through reid_set_knob)
+    const int tile = reid_knob(KNOB_GEMM_TILE) > 0 ? reid_knob(KNOB_GEMM_TILE) : 0;
+    p.dbg = reid_knob(KNOB_GEMM_DBG) > 0 ? reid_knob(KNOB_GEMM_DBG) : 0;
     if (tile == 2) return launch<256, 256, 2, 4>(p, s);
     if (tile == 3) return launch<128, 128, 2, 2>(p, s);
     if (tile == 8) return launch<128, 256, 2, 4>(p, s);
@@ -320,6 +319,23 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     // as the 256x256 tile's (~1.0-1.1 PF on these shapes) and, unlike one big workgroup per CU, one workgroup's stores
     // overlap the other's MFMAs (sum over the seven shapes: 1.90 ms vs 2.04-2.17 ms for 256x256 / 128x256 tiles).
     // (k2_group_n is a multiple of 128, so a column tile never straddles two LoRA groups of the fused q|k|v projection.)
+    // r02 anatomy of this kernel on the seven ViT shapes (profiles/r02_gemm_variants*.log, sum per layer, 1 MI355X):
+    //   whole kernel 1.93 ms = K loop alone 1.40-1.43 ms (REID_GEMM_DBG=1) + epilogue alone 0.59-0.60 ms (REID_GEMM_DBG=4): they do
+    //   NOT overlap although two workgroups share a CU.  K loop with the MFMAs removed (LDS-DMA + fragment reads only): 1.22 ms =
+    //   22 GB of L2->LDS operand traffic at 71 GB/s per CU, the per-CU LDS-DMA rate of MI355X_MICROARCH.md ("Indexed rows:
+    //   gather into LDS", 66-73 GB/s): the 128x128 K loop is bound by the CU's vector-memory path, not by the matrix pipe
+    //   (MFMAs + fragment reads without any LDS-DMA: 1.10 ms = 1.33 PF); the epilogue streams C / residual / aux at 4.2 TB/s and
+    //   needs the same path.  Tried in r02 and dropped (all measured in that harness, code in git history of this round):
+    //   * persistent two-workgroups-per-CU grid with the partner of each CU (blocks b and b+256, found with tools/hwinfo.hip via
+    //     HW_REG_LDS_ALLOC) started 0.5x..2.5x of a K-loop time late, next tile's first K-step prefetched under the epilogue:
+    //     1.99 ms unstaggered, 2.03-2.22 ms staggered (phasing the pair does not create overlap: they contend for that path);
+    //   * three-slot LDS ring with counted vmcnt + raw s_barrier, one 8-wave workgroup per CU (256x128, 128x256) or 128x128:
+    //     K loops 1.49-1.54 ms / 1.99 ms (eight barrier-coupled waves serialise their read and MFMA phases);
+    //   * epilogue through a wave-private LDS transpose (4 rows x 256 B per access instead of 16 rows x 64 B): epilogue alone
+    //     0.85 ms vs 0.60 ms -- segment length is not what holds the epilogue at 4.2 TB/s.
+    //   What is left is halving the operand traffic per flop (256x256 tiles) TOGETHER with a wave-group ping-pong K loop
+    //   and an epilogue that overlaps the next tile; the plain 256x256 / 128x256 tiles here lose more in the un-hidden
+    //   epilogue (2.27 / 2.15 ms) than their K loop gains (1.35 ms).
     // Tried and dropped in r01 (same harness): LDS-ring variants with 32-wide K steps and counted vmcnt (128x256 tile with 4
     // waves of 64x128, 128x128 with 2/3/4 stages at 2/3/4 workgroups per CU): 5-25 % slower than this on every shape;
     // a DPP lane exchange that makes the epilogue store 128 contiguous bytes per row: slower (the DPP hazards cost more

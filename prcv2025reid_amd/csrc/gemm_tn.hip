@@ -160,7 +160,7 @@ int launch_tn(TnParams& p, hipStream_t s) {
     // workgroups per launch: few, long-lived slabs (each pays its load latency once) -- 384 instead of 1536 took the small
     // products from 30 to 22 us stand-alone and 0.6 ms off the train step (less interference with the dX GEMMs; r01 sweep 128..6144)
     int target = 384;
-    { const char* e = getenv("REID_TN_BLOCKS"); if (e && atoi(e) > 0) target = atoi(e); }
+    if (reid_knob(KNOB_TN_BLOCKS) > 0) target = reid_knob(KNOB_TN_BLOCKS);
     int slabs = target / tiles;
     if (slabs < 1) slabs = 1;
     const int max_slabs = (p.M + 255) / 256;

@@ -445,7 +445,7 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     TopkParams p{};
     p.Q = (const bf16_t*)Q_bf16; p.G = (const bf16_t*)G_bf16; p.Nq = Nq; p.Ng = Ng; p.D = D;
     p.exq = exclude_q; p.exg = exclude_g; p.cap = cap;
-    { const char* e = getenv("REID_TOPK_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = reid_knob(KNOB_TOPK_DBG) > 0 ? reid_knob(KNOB_TOPK_DBG) : 0;
     p.tiles_m = (Nq + BM - 1) / BM;
     // phase A: sample = first ns gallery rows, dense scores, k-th best -> thr
     p.g_begin = 0; p.g_end = ns; p.thr = nullptr; p.dense = dense; p.ld_dense = ns;
@@ -463,12 +463,11 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     p.g_begin = 0; p.g_end = Ng; p.thr = thr; p.dense = nullptr;
     p.cand_idx = cidx; p.cand_score = cscore; p.cand_cnt = cnt;
     {
-        const char* e = getenv("REID_TOPK_TILE");
         // Filter-pass anatomy at 10k x 200k x 512 (REID_TOPK_DBG=1/2, r01): K loops 1.1-1.7 ms depending on the tile, compare of
         // every score against its row threshold 0.7 ms, candidate appends 0.6 ms; 128x128 / 128x256 / 256x128 tiles all end
         // at 4.0-4.1 ms per top-10 call.  Tried and dropped: a persistent variant with a 3-stage ring across tiles (4.02 ms: the
         // per-tile latency it removes is not the bottleneck), the 256x256 tile (fastest K loop, but its epilogue spills).
-        const int tile = e ? atoi(e) : 2;
+        const int tile = reid_knob(KNOB_TOPK_TILE) >= 0 ? reid_knob(KNOB_TOPK_TILE) : 2;
         int rc;
         if (tile == 1) rc = launch_filter<256, 128, 4, 2>(p, s);
         else if (tile == 3) rc = launch_filter<256, 256, 2, 4>(p, s);
@@ -735,7 +734,7 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
         const float* Q = Qf + (size_t)q0 * D;
         const int32_t* eq = exclude_q ? exclude_q + q0 : nullptr;
         // gallery rows per wave and iteration (the loads of all rows are issued before the first dot): 4 rows = 8 KiB in flight per wave at D = 512
-        static const int rows_env = [] { const char* e = getenv("REID_STREAM_ROWS"); return e ? atoi(e) : 0; }();
+        const int rows_env = reid_knob(KNOB_STREAM_ROWS);
 #define REID_STREAM_LAUNCH1(DJ, R, P) hipLaunchKernelGGL((stream_topk_kernel<DJ, R, P>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
 #define REID_STREAM_LAUNCH(DJ, R) do { if (nq == 1) REID_STREAM_LAUNCH1(DJ, R, 1); else if (nq == 2) REID_STREAM_LAUNCH1(DJ, R, 2); else REID_STREAM_LAUNCH1(DJ, R, 4); } while (0)
         switch (D / 256) {

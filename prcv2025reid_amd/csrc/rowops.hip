@@ -4,6 +4,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- error plumbing (shared by all files)
 static thread_local char g_err[512] = "";
@@ -14,7 +15,43 @@ void reid_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* reid_last_error(void) { return g_err; }
-extern "C" int reid_version(void) { return 100; }
+extern "C" int reid_version(void) { return 200; }
+
+// ---------------------------------------------------------------- experiment knobs (common.h)
+static const char* const g_knob_names[KNOB_COUNT] = {
+    "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM",
+    "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "SDM_IMPL"};
+static int g_knobs[KNOB_COUNT];
+static int* knob_table() {
+    static const bool init = [] {
+        for (int i = 0; i < KNOB_COUNT; ++i) {
+            char name[64];
+            snprintf(name, sizeof(name), "REID_%s", g_knob_names[i]);
+            const char* e = getenv(name);
+            g_knobs[i] = e ? atoi(e) : -1;          // -1 = "not set": every reader has its own default
+        }
+        return true;
+    }();
+    (void)init;
+    return g_knobs;
+}
+int reid_knob(int id) { return knob_table()[id]; }
+extern "C" int reid_set_knob(const char* name, int value) {
+    int* t = knob_table();
+    for (int i = 0; i < KNOB_COUNT; ++i)
+        if (strcmp(name, g_knob_names[i]) == 0) { t[i] = value; return REID_OK; }
+    reid_set_error("reid_set_knob: unknown knob %s", name);
+    return REID_ERR_ARG;
+}
+int reid_num_cus() {
+    static const int n = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
 extern "C" int reid_flavor(void) { return REID_FLAVOR_ID; }
 extern "C" int reid_check_device(int dev) {
     hipDeviceProp_t prop;

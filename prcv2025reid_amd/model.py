@@ -39,7 +39,7 @@ from .engine import TextEncodeFn, Engine, LoraLayout, VisionEncodeFn
 from .head import (MulFn, ActFn, AddFn, BNNeckFn, CrossEntropyLSFn, LayerNormF32Fn, LinearF32Fn, LinearNdF32Fn, MaskedMeanFn,
                    NanToNumFn, SDMFn, SmallAttnFn)
 from .tokenizer import load_tokenizer
-from .weights import param_spec, seeded_tensor, is_dead_key
+from .weights import param_spec, reference_init_state, seeded_tensor, is_dead_key
 
 logger = logging.getLogger(__name__)
 
@@ -101,8 +101,14 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self.layout = LoraLayout(self.arch)
         dev = torch.device(self.device)
         lora_host = torch.zeros(self.layout.size)
+        # Initial values: the reference's CONSTRUCTION semantics (weights.reference_init_state: lora_B = 0, lora_A
+        # kaiming-uniform, xavier SDM module, CLIP-derived patch convolutions + noise, ...) with seeded stand-ins where the
+        # reference would download CLIP; ``config.init = 'seeded'`` selects the all-random seeded fill the parity fixtures
+        # use (every tensor non-trivial, lora_B included, so no path is vacuously correct).
+        self._init_mode = getattr(config, 'init', 'reference')
+        init_state = reference_init_state(self.arch, None, seed) if self._init_mode == 'reference' else None
         for k, shp in param_spec(self.arch, None).items():
-            v = seeded_tensor(k, shp, seed)
+            v = init_state[k] if init_state is not None else seeded_tensor(k, shp, seed)
             if '.loras.' in k:
                 self._lora_put(lora_host, k, v)
             else:
@@ -112,6 +118,8 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self._ref[LORA_PARAM_NAME] = self.lora_arena
         self.engine = Engine(self.arch, self._ref, self.lora_arena, dev)
         self._plans = {}
+        self._plan_ids = {}
+        self._forced_keep = None       # tests only: fixed keep decisions of the next modality-dropout draws
         self._overlap_text = os.environ.get('REID_TEXT_STREAM', '1') != '0'
         # Stochastic regularisers of the reference's training forward (all inactive in eval mode):
         #   DropPath in the vision blocks (clip_backbone.py:137-141,204), dropout in the SDM module (hard-coded 0.1: model.py:35,43),
@@ -359,60 +367,83 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             sm = torch.ones(B, M, device=x.device)
         return MaskedMeanFn.apply(z, sm)
 
-    def _modality_dropout(self, names: List[str], masks: List[torch.Tensor]) -> List[torch.Tensor]:
-        """Batch-level modality dropout, models/model.py:434-474, on the masks that enter the fusion block.
+    def _modality_dropout(self, names: List[str], masks: List[torch.Tensor]):
+        """Batch-level modality dropout, models/model.py:434-474 -> (masks after the draw, keep flags or None, device flag).
 
-        The reference removes a dropped modality from the list it fuses; masking its slot for every sample is the same
-        function (a masked slot is no key, and its own output is excluded by the masked mean), keeps the shapes static and
-        lets the reference's safety rule -- cancel the whole draw if it would leave a sample without any valid modality --
-        run on the device without a host read-back.  'vis' is never dropped; one host draw per other modality, in order
-        (``torch.rand(1).item() > p`` keeps), as in the reference; inactive while epoch <= modality_dropout_warmup_epochs."""
+        The reference draws ``torch.rand(1).item() > p`` once per non-'vis' modality (in order), removes the dropped ones from
+        the fused list AND from ``feature_masks`` (so compute_loss skips their SDM pairs and counts validity over the kept
+        ones), cancels the whole draw if a sample would be left without any valid modality, and returns the single survivor
+        unfused when only 'vis' is kept.  Here the same function runs with static shapes and no host read-back: a dropped
+        modality's mask becomes all-zero (a masked slot is no attention key, its own output is excluded by the masked mean, an
+        all-zero mask makes compute_loss skip the modality exactly like a missing key), and the cancel rule is a device flag
+        ``ok`` that selects between the dropped and the original masks.  Inactive while epoch <= warm-up epochs."""
         cfg = self.config
         p = float(getattr(cfg, 'modality_dropout', 0.0))
         min_mod = int(getattr(cfg, 'min_modalities', 1))
         if self.current_epoch <= int(getattr(cfg, 'modality_dropout_warmup_epochs', 3)):
             p = 0.0
         if p <= 0.0 or len(names) <= min_mod:
-            return masks
-        keep = [m == 'vis' or float(torch.rand(1, generator=self._rng_host)) > p for m in names]
+            return masks, None, None
+        keep = self._forced_keep if self._forced_keep is not None else \
+            [m == 'vis' or float(torch.rand(1, generator=self._rng_host)) > p for m in names]
+        keep = [bool(k) or m == 'vis' for k, m in zip(keep, names)]
         if all(keep) or sum(keep) < min_mod:
-            return masks
+            return masks, None, None
         dev = masks[0].device
         kv = self.engine._const(('moddrop', tuple(keep)), lambda: torch.tensor([1.0 if k else 0.0 for k in keep]))
         stacked = torch.stack([m.to(dev).float() for m in masks], dim=1)             # [B, M]
         dropped = stacked * kv.view(1, -1)
         ok = ((dropped > 0).any(dim=1)).all()                                        # every sample keeps >= 1 valid modality
         final = torch.where(ok, dropped, stacked)
-        return [final[:, i].contiguous() for i in range(len(masks))]
+        return [final[:, i].contiguous() for i in range(len(masks))], keep, ok
 
     def _plan(self, images, modality_masks, B):
-        """{modality: (kind 'all' | 'some' | 'none', device row indices or None, device mask f32 [B])}."""
+        """{modality: (kind 'all' | 'some' | 'none', device row indices or None, device mask f32 [B])}.
+
+        Which rows of which modality go through the encoder sizes the packed batch, so it has to be known on the HOST.  Masks
+        given as host tensors (what the reference's collate produces) cost nothing.  Device-resident masks (train.py:742 moves
+        the whole batch) are looked up by tensor identity + version first -- a batch object reused across steps, or a replayed
+        graph, never copies -- and otherwise read back with ONE stacked device->host copy for all modalities (the reference
+        itself synchronises five times here: ``mask.sum() > 0`` per modality, model.py:367)."""
         dev = torch.device(self.device)
         names = [m for m in (images or {}) if m in self.vision_modalities] + ['text']
+        given = {m: (None if modality_masks is None else modality_masks.get(m)) for m in names}
+        ident = (B, tuple((m, None if t is None else ((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) if torch.is_tensor(t)
+                                                     else id(t))) for m, t in given.items()))
+        on_dev = [m for m, t in given.items() if torch.is_tensor(t) and t.is_cuda]
+        if on_dev:
+            hit = self._plan_ids.get(ident)
+            if hit is not None and all(given[m] is hit[1][m] for m in on_dev):       # same tensor objects, unmodified
+                return hit[0]
         host = {}
-        for m in names:
-            t = None if modality_masks is None else modality_masks.get(m)
-            if t is None:
-                host[m] = None
-            else:
-                host[m] = (t.detach().to('cpu') if torch.is_tensor(t) else torch.as_tensor(t)).float().contiguous()
+        if on_dev:
+            stacked = torch.stack([given[m].detach().float().reshape(-1) for m in on_dev], dim=0).to('cpu')   # one D2H copy
+            for i, m in enumerate(on_dev):
+                host[m] = stacked[i].contiguous()
+        for m, t in given.items():
+            if m in host:
+                continue
+            host[m] = None if t is None else (t.detach() if torch.is_tensor(t) else torch.as_tensor(t)).float().contiguous()
         key = (B, tuple((m, None if h is None else h.numpy().tobytes()) for m, h in host.items()))
         plan = self._plans.get(key)
-        if plan is not None:
-            return plan
-        plan = {}
-        for m, h in host.items():
-            if h is None:            # no mask given: text counts as present, an image modality without a mask is absent (model.py:367)
-                plan[m] = ('all', None, torch.ones(B, device=dev)) if m == 'text' else ('none', None, torch.zeros(B, device=dev))
-            elif float(h.sum()) <= 0 and m != 'text':
-                plan[m] = ('none', None, torch.zeros(B, device=dev))
-            elif bool(h.bool().all()):
-                plan[m] = ('all', None, h.to(dev))
-            else:
-                plan[m] = ('some', h.bool().nonzero().flatten().to(dev), h.to(dev))
-        if len(self._plans) > 32:
-            self._plans.clear()
-        self._plans[key] = plan
+        if plan is None:
+            plan = {}
+            for m, h in host.items():
+                if h is None:        # no mask given: text counts as present, an image modality without a mask is absent (model.py:367)
+                    plan[m] = ('all', None, torch.ones(B, device=dev)) if m == 'text' else ('none', None, torch.zeros(B, device=dev))
+                elif float(h.sum()) <= 0 and m != 'text':
+                    plan[m] = ('none', None, torch.zeros(B, device=dev))
+                elif bool(h.bool().all()):
+                    plan[m] = ('all', None, h.to(dev))
+                else:
+                    plan[m] = ('some', h.bool().nonzero().flatten().to(dev), h.to(dev))
+            if len(self._plans) > 32:
+                self._plans.clear()
+            self._plans[key] = plan
+        if on_dev:
+            if len(self._plan_ids) > 8:
+                self._plan_ids.clear()
+            self._plan_ids[ident] = (plan, {m: given[m] for m in on_dev})               # keeps the tensors alive: ids stay unique
         return plan
 
     # ------------------------------------------------------------------ forward
@@ -507,9 +538,15 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         else:
             sem = OrderedDict(raw.items())
         flist = list(sem.values()); mlist = [fmask[m] for m in sem]
+        keep = ok = None
         if self.training:
-            mlist = self._modality_dropout(list(sem.keys()), mlist)
+            mlist, keep, ok = self._modality_dropout(list(sem.keys()), mlist)
         fused = flist[0] if len(flist) == 1 else self._fusion(flist, mlist)
+        if keep is not None:
+            # masks after the draw are what compute_loss must see (model.py:466-468: dropped modalities leave feature_masks)
+            fmask = OrderedDict((m, mlist[i]) for i, m in enumerate(sem.keys()))
+            if sum(keep) == 1:        # only 'vis' survives: the reference returns it unfused (model.py:479-480) unless the draw is cancelled
+                fused = torch.where(ok, flist[list(sem.keys()).index('vis')], fused)
         out = {'features': fused, 'raw_modality_features': raw, 'modality_features': sem}
         if self.bn_neck is not None:
             P = self._ref
@@ -565,9 +602,8 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
                                                'classification_head', 'other_modules'))
         for name, p in self.named_parameters():
             if name.startswith('clip_encoder.'):
-                if 'clip_model' in name:
-                    if p.requires_grad:
-                        groups['clip_backbone'].append(p)
+                if 'clip_model' in name and p.requires_grad:
+                    groups['clip_backbone'].append(p)
                 elif 'lora' in name.lower():
                     groups['mer_loras'].append(p)
                 elif 'patch_embeds' in name:

@@ -10,7 +10,8 @@ redundantly and identically.  Consequences:
     negatives for SDM), not an average of per-rank losses;
   * no collective is needed in backward for the gather: rank r's feature gradient is rows r of the
     (replicated) global gradient;
-  * head parameters (bn_neck, sdm_module, fusion) get identical gradients on every rank -- no reduction;
+  * head parameters (bn_neck, sdm_module, fusion) get the same gradient on every rank up to the summation order of the
+    kernels' fp32 atomics; they are averaged in the small bucket so the replicas stay bit-identical (reduce_grads);
   * encoder-side parameters (the flat LoRA arena, null tokens) hold per-rank partial sums -> ONE
     all-reduce(SUM) of the flat arena (21 MB fp32 at r=8) + one tiny one for the null tokens.
     xGMI rings are per-link bound: t ~ 2(n-1)/n * 21 MB / 153 GB/s ~ 0.24 ms at n=8, <1 % of a step, so a
@@ -60,11 +61,13 @@ class DataParallel:
     Every rank must pass the same set of modalities (keys of ``images`` / presence of ``texts``).
     """
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, enabled: bool = True):
+        """``enabled=False``: behave as a single process even when torch.distributed is initialised (a rank running alone)."""
         self.model = model
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        on = enabled and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
 
     def _gather_fn(self, raw: "OrderedDict[str, torch.Tensor]", fmask: "OrderedDict[str, torch.Tensor]"):
         if self.world == 1:
@@ -98,24 +101,48 @@ class DataParallel:
         return [p for n, p in self.model.named_parameters()
                 if p.requires_grad and (n.startswith('clip_encoder.') or n.startswith('null_tokens.'))]
 
+    def head_params(self):
+        """Parameters of the redundantly evaluated head (bn_neck, sdm_module, feature_fusion)."""
+        return [p for n, p in self.model.named_parameters()
+                if p.requires_grad and not (n.startswith('clip_encoder.') or n.startswith('null_tokens.'))]
+
     def reduce_grads(self):
+        """Encoder-side gradients are per-rank partial sums -> all-reduce(SUM).  Head gradients are mathematically identical
+        on every rank, but the head kernels reduce with fp32 atomics (BN-neck statistics, LayerNorm dgamma/dbeta), so their
+        last bits differ from rank to rank; left alone the replicas would drift apart (Adam amplifies differences on
+        near-zero gradients).  They are therefore AVERAGED in the same small bucket: every rank steps with the same bits."""
         if self.world == 1:
             return
-        small = []
+        small, scale = [], []
         for p in self.encoder_side_params():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             if p.numel() >= (1 << 16):
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)     # the flat LoRA arena: one bucket
             else:
-                small.append(p)
+                small.append(p); scale.append(1.0)
+        for p in self.head_params():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            small.append(p); scale.append(1.0 / self.world)
         if small:
-            flat = torch.cat([p.grad.reshape(-1) for p in small])
+            flat = torch.cat([p.grad.reshape(-1) * s if s != 1.0 else p.grad.reshape(-1) for p, s in zip(small, scale)])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             o = 0
             for p in small:
                 n = p.numel()
                 p.grad.copy_(flat[o:o + n].view_as(p.grad)); o += n
+
+    def params_in_sync(self) -> float:
+        """max over parameters of (max over ranks - min over ranks) of the parameter values: 0.0 when the replicas agree
+        bit for bit (diagnostic for tests and the bench line)."""
+        if self.world == 1:
+            return 0.0
+        flat = torch.cat([p.detach().reshape(-1).double() for _, p in self.model.named_parameters() if p.requires_grad])
+        hi = flat.clone(); lo = flat.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        return float((hi - lo).abs().max())
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -166,6 +166,11 @@ class StepDriver:
         model.train()
         model.set_epoch(epoch)
         self.batch_idx = 0
+        # the reference builds grad_norms = [] inside train_epoch_fixed (train.py:698): its ">10 recorded norms" adaptive-clip rule
+        # restarts every epoch.  Same here: history count (state[5]) and the device-side batch counter (state[19]) go back to 0
+        # (two 4-byte device fills, no host sync).
+        self.opt.state[5:6].zero_()
+        self.opt.state[19:20].zero_()
         if scale_fn is not None:
             self.opt.set_lrs(scale_fn, epoch - 1)            # LambdaLR counts epochs from 0, the loop from 1
 
@@ -187,6 +192,9 @@ class GraphedStep:
     captured ONCE as a HIP graph and replayed: ~900 kernel launches become one graph launch, which removes the host-side
     dispatch gaps between the many small kernels of the head and the step driver (measured with rocprofv3: 5-6 ms of idle
     GPU per 52 ms step in eager mode).
+
+    NOTE: construction runs ``warmup`` REAL optimizer steps on the sample batch (lazy initialisation, routing plan, allocator
+    pools) before the capture -- parameters, moments and the step count advance by that many steps.
 
     Constraints of a captured step: single process (collectives are left to the eager path), ``accum_steps == 1``, static
     shapes -- the batch layout AND the modality-mask pattern are part of the graph (masked rows are compacted on the host

@@ -174,6 +174,83 @@ def seeded_state(arch: dict, num_classes, seed: int) -> "OrderedDict[str, torch.
     return OrderedDict((k, seeded_tensor(k, shp, seed)) for k, shp in param_spec(arch, num_classes).items())
 
 
+# ---------------------------------------------------------------------------------------------------- construction semantics
+def reference_init_state(arch: dict, num_classes, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    """Fresh fp32 CPU state dict with the reference's CONSTRUCTION semantics (what a freshly built reference model holds):
+
+    * tensors the reference takes from pretrained CLIP (text tower, the shared linears / LayerNorms of the MER blocks,
+      position / class embeddings, the two projections, the 'vis' patch convolution) -- the hub is unreachable here, so they
+      are the seeded stand-ins of :func:`seeded_tensor` (load real ones with checkpoint.load_clip_pretrained);
+    * LoRA: ``lora_A`` kaiming-uniform(a=sqrt 5) = U(+-1/sqrt(fan_in)), ``lora_B`` ZERO, so the initial low-rank update is
+      exactly 0 (mer_lora.py:36-38);
+    * patch convolutions of the other modalities = the CLIP ('vis') one -- channel mean for the one-channel nir / sk -- plus
+      N(0, 0.02^2) noise on the weight and N(0, 0.01^2) on the bias (patch_embeds.py:78-105,150-167);
+    * SDM module: xavier-uniform Linear / in_proj weights, zero biases (model.py:50-55); fusion block: torch's defaults
+      (xavier in_proj, kaiming-uniform(a=sqrt 5) Linears with U(+-1/sqrt(fan_in)) biases, zero MHA biases);
+      LayerNorms (1, 0); null tokens N(0, 0.02^2) (model.py:300-303); BN-neck as models/model.py:196-206.
+    Every draw comes from the per-key seeded generator, so the result does not depend on iteration order."""
+    import math
+
+    def gen(key):
+        g = torch.Generator(device='cpu')
+        g.manual_seed((int(seed) * 1000003 + zlib.crc32(('init:' + key).encode())) % (2 ** 63 - 1))
+        return g
+
+    def uniform(key, shape, bound):
+        return (torch.rand(tuple(shape), generator=gen(key), dtype=torch.float32) * 2.0 - 1.0) * bound
+
+    def normal(key, shape, std):
+        return torch.randn(tuple(shape), generator=gen(key), dtype=torch.float32) * std
+
+    out = OrderedDict()
+    spec = param_spec(arch, num_classes)
+    ce = 'clip_encoder.'
+    vis_w = seeded_tensor(f'{ce}patch_embeds.vis.proj.weight', spec[f'{ce}patch_embeds.vis.proj.weight'], seed)
+    for k, shp in spec.items():
+        if '.lora_A.' in k:
+            v = uniform(k, shp, 1.0 / math.sqrt(shp[1]))
+        elif '.lora_B.' in k:
+            v = torch.zeros(shp)
+        elif k.startswith(ce + 'patch_embeds.'):
+            m = k.split('.')[2]
+            fan_in = spec[f'{ce}patch_embeds.{m}.proj.weight'][1] * shp[-1] * shp[-1] if k.endswith('weight') else None
+            if k.endswith('weight'):
+                base = vis_w if shp[1] == 3 else vis_w.mean(dim=1, keepdim=True)
+                v = base.clone() if m == 'vis' else base + normal(k, shp, 0.02)
+            else:                              # HF CLIP's patch convolution has no bias: each module keeps its own default draw
+                w_shape = spec[f'{ce}patch_embeds.{m}.proj.weight']
+                bound = 1.0 / math.sqrt(w_shape[1] * w_shape[2] * w_shape[3])
+                v = uniform(k, shp, bound)
+                if m != 'vis':
+                    v = v + normal(k + ':noise', shp, 0.01)
+        elif k.startswith('sdm_module.') or k.startswith('feature_fusion.'):
+            ln = ('semantic_proj.1.', 'feature_fusion.mlp.0.', 'feature_fusion.norm1.', 'feature_fusion.norm2.')
+            if any(t in k for t in ln):
+                v = torch.ones(shp) if k.endswith('weight') else torch.zeros(shp)
+            elif k.endswith('in_proj_weight') or (k.startswith('sdm_module.') and k.endswith('weight')):
+                v = uniform(k, shp, math.sqrt(6.0 / (shp[0] + shp[1])))                   # xavier_uniform
+            elif k.endswith('in_proj_bias') or k.endswith('out_proj.bias') or k.startswith('sdm_module.'):
+                v = torch.zeros(shp)
+            elif k.endswith('weight'):
+                v = uniform(k, shp, 1.0 / math.sqrt(shp[1]))                              # nn.Linear default
+            else:
+                fan_in = spec[k[:-4] + 'weight'][1]
+                v = uniform(k, shp, 1.0 / math.sqrt(fan_in))
+        elif k.startswith('null_tokens.'):
+            v = normal(k, shp, 0.02)
+        elif k.startswith('bn_neck.'):
+            if k.endswith('bn.weight') or k.endswith('running_var'):
+                v = torch.ones(shp)
+            elif k.endswith('bn.bias') or k.endswith('running_mean'):
+                v = torch.zeros(shp)
+            else:
+                v = normal(k, shp, 0.001)
+        else:
+            v = seeded_tensor(k, shp, seed)
+        out[k] = v
+    return out
+
+
 def fingerprint(state: Dict[str, torch.Tensor], keys=None) -> float:
     """Order-independent checksum used by fixtures to detect RNG drift."""
     tot = 0.0

@@ -47,6 +47,8 @@ from prcv2025reid_amd.config import TrainingConfig, arch_of            # noqa: E
 from prcv2025reid_amd.tokenizer import HashTokenizer                    # noqa: E402
 from prcv2025reid_amd.weights import seeded_fill, fingerprint, param_spec  # noqa: E402
 from prcv2025reid_amd.synthetic import synthetic_batch                  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from helpers import edge_inputs, MODDROP_CASES                          # noqa: E402  (the same input recipe the tests use)
 
 
 RANDOMIZE_HF = False
@@ -118,7 +120,22 @@ GRAD_KEEP_FULLTRAIN = GRAD_KEEP + (
     'text_model.encoder.layers.0.self_attn.q_proj.bias')
 
 
-def run_case(name, cfg, *, num_classes, wseed, dseed, P, K, mask_drop, training, freeze, keep):
+class _ForcedRand:
+    """Stands in for ``torch.rand`` while the reference's forward runs: ``torch.rand(1)`` (the modality-dropout draw,
+    model.py:450) returns the next forced value; every other call goes to the real function."""
+
+    def __init__(self, values):
+        self.values = list(values); self.real = torch.rand; self.used = 0
+
+    def __call__(self, *size, **kw):
+        if size == (1,) and not kw and self.values:
+            self.used += 1
+            return torch.tensor([self.values.pop(0)])
+        return self.real(*size, **kw)
+
+
+def run_case(name, cfg, *, num_classes, wseed, dseed, P, K, mask_drop, training, freeze, keep, variant=None, forced=None,
+             epoch=None):
     print(f'[{name}] building reference ...', flush=True)
     a = arch_of(cfg)
     model = build_reference(cfg, num_classes, wseed)
@@ -126,13 +143,24 @@ def run_case(name, cfg, *, num_classes, wseed, dseed, P, K, mask_drop, training,
     model.train(training)
     if freeze:
         apply_freeze_rule(model)
-    model.set_epoch(getattr(cfg, 'golden_epoch', 2))
+    model.set_epoch(epoch if epoch is not None else getattr(cfg, 'golden_epoch', 2))
     out = {}
     spec = param_spec(a, num_classes)
     sd = model.state_dict()
     out['weights_fingerprint'] = np.float64(fingerprint({k: sd[k] for k in spec}))
+    images, texts, masks = edge_inputs(batch, variant)
     with torch.set_grad_enabled(training):
-        o = model(images=batch['images'], texts=batch['texts'], modality_masks=batch['modality_mask'])
+        if forced is not None:
+            fr = _ForcedRand(forced)
+            torch.rand = fr
+            try:
+                o = model(images=images, texts=texts, modality_masks=masks)
+            finally:
+                torch.rand = fr.real
+            out['forced_used'] = np.int64(fr.used)
+        else:
+            o = model(images=images, texts=texts, modality_masks=masks)
+        out['fused_modalities'] = np.array(list(o['modality_features'].keys()))
         for k in ('features', 'bn_features', 'logits'):
             out[k] = o[k].detach().numpy()
         for m, t in o['raw_modality_features'].items():
@@ -186,8 +214,53 @@ def full_cfg(rank):
                           modality_dropout=0.0)
 
 
+def moddrop_cfg():
+    c = tiny_cfg(4)
+    c.modality_dropout = 0.5
+    c.modality_dropout_warmup_epochs = 3
+    return c
+
+
+def make_edge_cases():
+    """Reference outputs for the forward edge cases and for fixed modality-dropout draws (tiny architecture, train mode)."""
+    for v in ('nomask', 'single', 'textonly', 'deadrow'):
+        run_case(f'tiny_edge_{v}', tiny_cfg(4), num_classes=5, wseed=14, dseed=24, P=3, K=2, mask_drop=0.3,
+                 training=True, freeze=True, keep=('null_tokens.', 'bn_neck.'), variant=v)
+    run_case('tiny_edge_single_eval', tiny_cfg(4), num_classes=5, wseed=14, dseed=24, P=3, K=2, mask_drop=0.3,
+             training=False, freeze=True, keep=(), variant='single')
+    # forced draws (keep iff value > 0.5), order nir, sk, cp, text; epoch 5 > warm-up 3
+    #   A: drop nir + cp (masks all-on, so nobody is left empty)       B: drop everything but vis -> unfused vis feature
+    #   C: 30 % masked batch with vis missing on rows 0 and 3: dropping all non-vis would empty them -> draw cancelled
+    for name, (forced, mask_drop, variant) in MODDROP_CASES.items():
+        run_case(name, moddrop_cfg(), num_classes=5, wseed=15, dseed=25, P=3, K=2, mask_drop=mask_drop, training=True,
+                 freeze=True, keep=('null_tokens.', 'bn_neck.'), forced=list(forced), epoch=5, variant=variant)
+
+
+def make_param_groups():
+    """learnable_params.json: the reference's optimiser groups (models/model.py:661-729, clip_backbone.py:342-371): group
+    names, learning rates and member parameter names, as constructed and after train.py's freeze rule."""
+    import json
+    out = {}
+    for tag, cfg, C in (('tiny', tiny_cfg(4), 5), ('full', full_cfg(8), 16)):
+        for frozen in (False, True):
+            m = build_reference(cfg, C, 0)
+            if frozen:
+                apply_freeze_rule(m)
+            names = {id(p): n for n, p in m.named_parameters()}
+            groups = []
+            for g in m.get_learnable_params():
+                groups.append({'name': g['name'], 'lr': float(g['lr']), 'params': [names[id(p)] for p in g['params']],
+                               'trainable': [bool(p.requires_grad) for p in g['params']]})
+            out[f'{tag}_{"frozen" if frozen else "built"}'] = groups
+            print(f'[param_groups/{tag}/{"frozen" if frozen else "built"}] ' +
+                  ', '.join(f"{g['name']}:{len(g['params'])}@{g['lr']}" for g in groups))
+    json.dump(out, open(os.path.join(HERE, 'learnable_params.json'), 'w'))
+
+
 def make_model_cases(which):
     if which in (None, 'tiny'):
+        run_case('tiny_train_r16_masked', tiny_cfg(16), num_classes=5, wseed=16, dseed=26, P=3, K=2, mask_drop=0.3,
+                 training=True, freeze=True, keep=GRAD_KEEP)
         run_case('tiny_train_frozen', tiny_cfg(4), num_classes=5, wseed=11, dseed=21, P=3, K=2, mask_drop=0.3,
                  training=True, freeze=True, keep=GRAD_KEEP)
         run_case('tiny_train_all', tiny_cfg(8), num_classes=7, wseed=12, dseed=22, P=4, K=2, mask_drop=0.0,
@@ -203,6 +276,11 @@ def make_model_cases(which):
                  training=True, freeze=True, keep=GRAD_KEEP)
         run_case('full_eval_r8', full_cfg(8), num_classes=16, wseed=2, dseed=4, P=4, K=2, mask_drop=0.3,
                  training=False, freeze=True, keep=())
+    if which in (None, 'full', 'full16'):
+        # BASELINE config 5 flavour at CPU size: r=16 (alpha/r = 1/16, mer_lora.py:27), 30 % mask drop, TRAIN mode
+        run_case('full_p4k2_r16_masked', full_cfg(16), num_classes=16, wseed=5, dseed=6, P=4, K=2, mask_drop=0.3,
+                 training=True, freeze=True, keep=('null_tokens.', 'bn_neck.', 'vision_layers.0.attn.q_proj.loras.nir',
+                                                   'vision_layers.11.mlp.fc1.loras.cp'))
 
 
 # --------------------------------------------------------------------------- retrieval
@@ -424,13 +502,17 @@ def _build_plain(cfg, num_classes):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'retrieval', 'statekeys', 'pipeline'])
+    ap.add_argument('--only', default=None, choices=[None, 'tiny', 'full', 'full16', 'retrieval', 'statekeys', 'pipeline', 'edge', 'groups'])
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.only in (None, 'retrieval'):
         make_retrieval_cases()
-    if args.only in (None, 'tiny', 'full'):
+    if args.only in (None, 'tiny', 'full', 'full16'):
         make_model_cases(args.only)
+    if args.only in (None, 'edge'):
+        make_edge_cases()
+    if args.only in (None, 'groups'):
+        make_param_groups()
     if args.only in (None, 'statekeys'):
         make_state_keys()
     if args.only in (None, 'pipeline'):

@@ -42,6 +42,47 @@ def case_inputs(meta):
     return cfg, arch, state, batch, tokens
 
 
+def edge_inputs(batch, variant):
+    """(images, texts, masks) of the reference call for an edge-case ``variant`` (model.py:367,386-389 no masks; :125-126,
+    479-480 single modality; :141-149 all-masked row; :417-418 text default mask).  Shared with the tests."""
+    images, texts, masks = batch['images'], batch['texts'], batch['modality_mask']
+    if variant == 'nomask':
+        return images, texts, None
+    if variant == 'single':
+        return {'vis': images['vis']}, None, {'vis': masks['vis']}
+    if variant == 'textonly':
+        return None, texts, None
+    if variant == 'novis03':                      # rows 0 and 3 have no RGB image (their other modalities stay)
+        masks = {m: t.clone() for m, t in masks.items()}
+        images = {m: t.clone() for m, t in images.items()}
+        for i in (0, 3):
+            masks['vis'][i] = 0.0; images['vis'][i] = 0.0
+            masks['nir'][i] = 1.0
+        return images, texts, masks
+    if variant == 'deadrow':                      # sample 1 has no valid modality at all
+        masks = {m: t.clone() for m, t in masks.items()}
+        images = {m: t.clone() for m, t in images.items()}
+        texts = list(texts)
+        for m in masks:
+            masks[m][1] = 0.0
+        for m in images:
+            images[m][1] = 0.0
+        texts[1] = ''
+        return images, texts, masks
+    return images, texts, masks
+
+
+
+# fixed modality-dropout draws of the reference-generated fixtures: name -> (forced torch.rand(1) values in the order
+# nir, sk, cp, text -- keep iff value > p = 0.5 --, mask_drop of the batch, input variant); epoch 5 > warm-up 3
+MODDROP_CASES = {
+    'tiny_moddrop_a': ((0.1, 0.9, 0.2, 0.8), 0.0, None),        # nir and cp dropped
+    'tiny_moddrop_b': ((0.1, 0.2, 0.3, 0.4), 0.0, None),        # everything but vis dropped -> unfused vis feature
+    'tiny_moddrop_c': ((0.1, 0.2, 0.3, 0.4), 0.3, 'novis03'),   # would leave rows 0 and 3 empty -> the draw is cancelled
+    'tiny_moddrop_d': ((0.9, 0.2, 0.8, 0.1), 0.3, None),        # sk and text dropped from a 30 % masked batch
+}
+
+
 def check_fingerprint(z, state):
     got = fingerprint(state)
     want = float(z['weights_fingerprint'])

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(libs, flavor):
     h = libs[flavor]
     missing = [n for n in header_functions() if not hasattr(h, n)]
     assert not missing, missing
-    assert h.reid_version() == 100
+    assert h.reid_version() == 200              # round 2 ABI (reid_set_knob, fused SDM)
     assert h.reid_flavor() == (1 if flavor == 'f16' else 0)
 
 

@@ -3,11 +3,11 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_case, case_inputs, check_fingerprint, maxdiff
+from helpers import load_case, case_inputs, check_fingerprint, maxdiff, edge_inputs, MODDROP_CASES
 from oracle import reid_oracle as O
 
 
-def _run_oracle(name, need_grad):
+def _run_oracle(name, need_grad, variant=None, keep=None):
     z, meta = load_case(name)
     cfg, arch, state, batch, tokens = case_inputs(meta)
     check_fingerprint(z, state)
@@ -17,11 +17,19 @@ def _run_oracle(name, need_grad):
             if t.dtype.is_floating_point and 'running_' not in k:
                 if not meta['freeze'] or ('loras' in k or 'bn_neck' in k or 'null_tokens' in k):
                     t.requires_grad_(True)
-    out = O.forward(state, arch, batch['images'], tokens, batch['modality_mask'], training)
+    images, texts, masks = edge_inputs(batch, variant)
+    if texts is not None and variant is not None:
+        from prcv2025reid_amd.tokenizer import HashTokenizer
+        tok = HashTokenizer(arch['text_vocab'], arch['text_bos_id'], arch['text_eos_id'], arch['text_max_len'])
+        tokens = tok(texts, padding=True, truncation=True, max_length=77)
+    out = O.forward(state, arch, images, tokens if texts is not None else None, masks, training, moddrop_keep=keep)
     return z, meta, state, batch, out
 
 
 def _check_outputs(z, out, tol):
+    if 'fused_modalities' in z.files:        # which modalities reached the fusion block / the loss (dropout removes some)
+        assert list(out['modality_features'].keys()) == [str(x) for x in z['fused_modalities']]
+        assert sorted(out['feature_masks'].keys()) == sorted(k[6:] for k in z.files if k.startswith('fmask.'))
     for k in ('features', 'bn_features', 'logits'):
         assert maxdiff(out[k].detach(), z[k]) < tol, k
     for m, t in out['raw_modality_features'].items():
@@ -54,10 +62,39 @@ def _check_train(z, meta, state, batch, out, tol, gtol):
             scale = max(1e-12, float(np.abs(ref).max()))
             assert maxdiff(g, ref) <= gtol * scale + 1e-9, f
             n += 1
-    assert n > 10
+    assert n > 10 or not meta.get('many_grads', 1)
 
 
-@pytest.mark.parametrize('name', ['tiny_train_frozen', 'tiny_train_all'])
+@pytest.mark.parametrize('variant', ['nomask', 'single', 'textonly', 'deadrow'])
+def test_oracle_edge_cases(variant):
+    """Reference quirks of forward(): no masks => no image is encoded (model.py:367,386-389); one modality => identity
+    fusion (:125-126,479-480); a sample without any valid modality => global mean in slot 0 (:141-149) and no CE term;
+    text without a mask => all valid (:417-418)."""
+    z, meta, state, batch, out = _run_oracle(f'tiny_edge_{variant}', True, variant=variant)
+    _check_outputs(z, out, 5e-5)        # (B = 6 batch-statistics BN magnifies fp32 summation-order noise: 2.1e-5 seen on 'single')
+    meta['many_grads'] = 0
+    _check_train(z, meta, state, batch, out, 2e-5, 2e-4)
+
+
+def test_oracle_edge_single_eval():
+    z, meta, state, batch, out = _run_oracle('tiny_edge_single_eval', False, variant='single')
+    _check_outputs(z, out, 2e-5)
+    assert maxdiff(out['features'], out['raw_modality_features']['vis']) == 0.0       # identity: no fusion, no SDM module in eval
+
+
+@pytest.mark.parametrize('name', sorted(MODDROP_CASES))
+def test_oracle_modality_dropout_fixed_draws(name):
+    """Batch-level modality dropout (model.py:434-474) with the reference's draws fixed by the fixture generator."""
+    forced, _, variant = MODDROP_CASES[name]
+    keep = dict(zip(('nir', 'sk', 'cp', 'text'), [v > 0.5 for v in forced]))
+    z, meta, state, batch, out = _run_oracle(name, True, variant=variant, keep=keep)
+    assert int(z['forced_used']) == 4
+    _check_outputs(z, out, 5e-5)
+    meta['many_grads'] = 0
+    _check_train(z, meta, state, batch, out, 2e-5, 2e-4)
+
+
+@pytest.mark.parametrize('name', ['tiny_train_frozen', 'tiny_train_all', 'tiny_train_r16_masked'])
 def test_oracle_tiny_train(name):
     z, meta, state, batch, out = _run_oracle(name, True)
     _check_outputs(z, out, 2e-5)
@@ -78,11 +115,12 @@ def test_oracle_tiny_eval():
     assert float((n - 8.0).abs().max()) < 1e-4           # SURVEY 8c known answer (4)
 
 
-@pytest.mark.parametrize('name', ['full_p4k2_r4', 'full_p4k2_r8_masked'])
+@pytest.mark.parametrize('name', ['full_p4k2_r4', 'full_p4k2_r8_masked', 'full_p4k2_r16_masked'])
 def test_oracle_full_train(name):
     torch.set_num_threads(8)
     z, meta, state, batch, out = _run_oracle(name, True)
     _check_outputs(z, out, 1e-4)
+    meta['many_grads'] = int(name != 'full_p4k2_r16_masked')
     _check_train(z, meta, state, batch, out, 1e-4, 1e-3)
 
 

@@ -33,12 +33,25 @@ cases = [
  ('fc1b bf16 K=3072      ', 2.0*M*d*(ff+Rp), lambda: ops.gemm(gact, W2, dh, A2=T[:, :Rp], B2=Bo, K2=Rp)),
  ('qkvb bf16 K=2304+96   ', 2.0*M*d*(3*d+3*Rp), lambda: ops.gemm(qkv, rnd(d, 3*d, scale=0.03), dh, A2=T, B2=rnd(d, 3*Rp, scale=0.1), K2=3*Rp)),
 ]
-tiles = [int(t) for t in os.environ.get('TILES', '0,2').split(',')]
+# variants = knob settings, e.g. VARIANTS="base:GEMM_PERSIST=0;pers:GEMM_PERSIST=1,GEMM_STAGGER=0;stag:GEMM_PERSIST=1,GEMM_STAGGER=100"
+import ctypes
+def set_knobs(spec):
+    for kv in spec.split(','):
+        if kv:
+            k, v = kv.split('=')
+            _lib.check(_lib.lib().reid_set_knob(k.encode(), int(v)))
+variants = [v.split(':') for v in os.environ.get('VARIANTS', 'base:GEMM_PERSIST=0;stag:GEMM_PERSIST=1').split(';')]
+knobs = sorted({kv.split('=')[0] for _, spec in variants for kv in spec.split(',') if kv})
+tot = {n: 0.0 for n, _ in variants}
 for name, fl, fn in cases:
     res = []
     for rnd_ in range(3):                      # interleaved rounds in ONE process (cdna guide rule 24)
-        for t in tiles:
-            os.environ['REID_GEMM_TILE'] = str(t)
-            res.append((t, timeit(fn, reps=5)))
-    best = {t: min(u for tt, u in res if tt == t) for t in tiles}
-    print(name + ': ' + '  '.join(f'tile{t}: {best[t]:7.1f} us {fl/best[t]/1e6:6.1f} TF' for t in tiles), flush=True)
+        for vn, spec in variants:
+            for k in knobs:
+                _lib.check(_lib.lib().reid_set_knob(k.encode(), -1))
+            set_knobs(spec)
+            res.append((vn, timeit(fn, reps=5)))
+    best = {vn: min(u for tt, u in res if tt == vn) for vn, _ in variants}
+    for vn in best: tot[vn] += best[vn]
+    print(name + ': ' + '  '.join(f'{vn}: {best[vn]:7.1f} us {fl/best[vn]/1e6:6.1f} TF' for vn, _ in variants), flush=True)
+print('sum over the seven shapes: ' + '  '.join(f'{vn}: {tot[vn]:7.1f} us' for vn, _ in variants), flush=True)
