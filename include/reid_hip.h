@@ -212,22 +212,31 @@ int reid_ce_ls_bwd(const float* logits, int32_t ld, const int64_t* labels, const
                    int32_t C, float smoothing, const float* grad_scale, float* dlogits, int32_t lddl, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * SDM loss (sdm_loss_stable, models/sdm_loss.py:13-149) between one modality and vis:
- *   q [N, D], g [Mg, D] f32; q_valid/g_valid uint8 (rows that take part, models/model.py:570,595);
- *   positives y[i,j] = (q_label[i] == g_label[j]) (models/model.py:605); tau clamped to [0.15, 0.5];
- *   S = qn.gn^T/tau clamped to +-20; result[0] = 0.5*(mean_rows CE(q->g) + mean_cols CE(g->q)) over
- *   rows/cols with >= 1 positive; result[1] = 1 if the pair contributes (any positive), else 0.
- *   No N x Mg matrix is written to HBM in fwd; ws holds 2*(N+Mg)+2 floats of row/col statistics.
- *   bwd: dq, dg (+= into f32 [*, D]) for upstream grad `gscale[0]` (device scalar).
+ * Fused SDM loss (sdm_loss_stable, models/sdm_loss.py:13-149) for ALL modality pairs of a step (models/model.py:586-622
+ * calls it once per non-vis modality against vis):
+ *   q [P*N, D] f32 = the P query sides stacked (rows [p*N, (p+1)*N) = pair p), g [Mg, D] f32 = the shared vis side;
+ *   q_label [N] (the batch labels, shared by the pairs), g_label [Mg]; q_valid [P*N] / g_valid [Mg] uint8 or NULL (rows that
+ *   take part, models/model.py:570,595); positives y[i,j] = (q_label[i] == g_label[j]) (models/model.py:605);
+ *   tau clamped to [0.15, 0.5] (:28); unit vectors with eps 1e-8 (:31-32); S = q^ g^T / tau clamped to +-20 (:86,94).
+ *   result[2p]   = 0.5 * (mean over rows with a positive of CE(q->g) + mean over such columns of CE(g->q))  (:34-70,121-123)
+ *   result[2p+1] = 1 if pair p has any positive (it contributes to the modality mean), else 0 and result[2p] = 0 (:105-106).
+ * S is never materialised: each tile of it exists only in MFMA accumulators (v_mfma_f32_32x32x2_f32 on the fp32 unit
+ * vectors, exact fp32) and is reduced to per-tile row / column partial sums that a second small launch adds in a fixed order;
+ * the backward pass recomputes the tiles.  No N x Mg array exists in fwd or bwd.
+ *   ws (reid_sdm_ws_floats(P, N, Mg, D) floats, kept from fwd to bwd):
+ *     unit vectors (P N + Mg) D | {lse, #pos} per row and column 2 P (N + Mg) | 4 P sums | P (N + Mg) loss terms |
+ *     max( per-tile partials 4 (tiles_n P N + tiles_m P Mg),  gradient accumulators (P N + Mg) D )      [tiles of 64 or 128]
+ *   bwd: dq [P*N, D] and dg [Mg, D] (+= into f32) for the upstream gradients gscale[p] (device array [P]).
+ * Requirements: D % 32 == 0, 32 <= D <= 1024.
  * ------------------------------------------------------------------------------------------ */
 int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label,
-                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg,
+                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t P, int32_t N, int32_t Mg,
                  int32_t D, float tau, float* ws, float* result, void* stream);
 int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label,
-                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg,
-                 int32_t D, float tau, const float* ws, const float* gscale, float* dq, int32_t lddq, float* dg,
+                 const int64_t* g_label, const uint8_t* q_valid, const uint8_t* g_valid, int32_t P, int32_t N, int32_t Mg,
+                 int32_t D, float tau, float* ws, const float* gscale, float* dq, int32_t lddq, float* dg,
                  int32_t lddg, void* stream);
-int64_t reid_sdm_ws_floats(int32_t N, int32_t Mg);
+int64_t reid_sdm_ws_floats(int32_t P, int32_t N, int32_t Mg, int32_t D);
 
 /* ------------------------------------------------------------------------------------------
  * Retrieval (train.py:499 + :463; tools/eval_mm_protocol.py:50-53,401-423,622-625):

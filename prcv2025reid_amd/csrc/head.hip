@@ -315,211 +315,6 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
-// ------------------------------------------------------------------------------------------ SDM
-// Row statistics of one side of the similarity matrix S [R, Cn] (row-major): for rows that take part,
-// lse over participating columns, number of positives, mean positive score, the row's loss term.  stat[r] = {lse, npos}
-// is kept for the backward pass.  SDM_RPW rows per wave, ONE pass over each row: 16-byte loads of S (and of the int64
-// labels, which stay in L2), per-lane partial sums combined over the wave at the end.  HBM-bound: 4 bytes per entry.
-// Every score that enters a softmax here has been clamped to [-20, 20] (models/sdm_loss.py:94), so sum_j exp(v_j) needs no
-// running maximum: at most 8e8 * Cn, far inside fp32 range, and a constant shift would not change the relative rounding of the
-// terms.  lse = log(sum exp(v)).  Per entry: clamp, exp, add -- the pass is VALU-light enough to stay HBM-bound.
-struct SdmRun { float se, npos, ps; };
-__device__ __forceinline__ void sdm_visit4(SdmRun& r, const f32x4 raw, uint32_t cv, const longlong2 l0, const longlong2 l1, long y) {
-    float v[4];
-    const bool ok[4] = {(cv & 0xffu) != 0, (cv & 0xff00u) != 0, (cv & 0xff0000u) != 0, (cv & 0xff000000u) != 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        v[k] = fminf(fmaxf(raw[k], -20.f), 20.f);
-        r.se += ok[k] ? __expf(v[k]) : 0.f;
-    }
-    // positives are rare: test the low label words first, the full 64-bit compare only in waves that saw a match
-    const int yl = (int)y;
-    if (((int)l0.x == yl) | ((int)l0.y == yl) | ((int)l1.x == yl) | ((int)l1.y == yl)) {
-        const bool pos[4] = {l0.x == y, l0.y == y, l1.x == y, l1.y == y};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ok[k] && pos[k]) { r.npos += 1.f; r.ps += v[k]; }
-    }
-}
-__device__ __forceinline__ void sdm_visit(SdmRun& r, float raw, bool valid, bool pos) {
-    if (!valid) return;
-    const float v = fminf(fmaxf(raw, -20.f), 20.f);
-    r.se += __expf(v);
-    if (pos) { r.npos += 1.f; r.ps += v; }
-}
-
-constexpr int SDM_RPW = 2;     // rows per wave: the column labels / validity bytes (L2) are read once per SDM_RPW rows
-__global__ __launch_bounds__(256) void sdm_side_kernel(const float* __restrict__ S, int ld, const int64_t* __restrict__ rlab,
-                                                       const int64_t* __restrict__ clab, const uint8_t* __restrict__ rvalid,
-                                                       const uint8_t* __restrict__ cvalid, int R, int Cn, float* __restrict__ stat,
-                                                       float* __restrict__ row_loss) {
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SDM_RPW;
-    if (row0 >= R) return;
-    const float* s[SDM_RPW]; long y[SDM_RPW]; bool live[SDM_RPW]; SdmRun r[SDM_RPW];
-#pragma unroll
-    for (int a = 0; a < SDM_RPW; ++a) {
-        const int row = min(row0 + a, R - 1);
-        s[a] = S + (size_t)row * ld;
-        y[a] = rlab[row];
-        live[a] = row0 + a < R && (!rvalid || rvalid[row]);
-        r[a] = SdmRun{0.f, 0.f, 0.f};
-    }
-    const bool vec = (ld & 3) == 0 && (((uintptr_t)S | (uintptr_t)clab) & 15) == 0 && (!cvalid || ((uintptr_t)cvalid & 3) == 0);
-    const int n4 = vec ? Cn >> 2 : 0;
-    // Rows are a power-of-two stride apart when Cn is: waves that all start at column 0 would walk the HBM channels in
-    // lockstep.  Each wave starts at its own rotation of the row (only the order of the sums changes).
-    const int niter = (n4 + 63) >> 6;
-    const int rot = niter > 1 ? (int)(((unsigned)row0 / SDM_RPW * 7u) % (unsigned)niter) : 0;
-    constexpr int U = 4;           // chunks in flight per wave: all loads of U chunks are issued before the first is consumed
-    for (int i0 = 0; i0 < niter; i0 += U) {
-        f32x4 v[U][SDM_RPW]; longlong2 l0[U], l1[U]; uint32_t cv[U]; bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int it = i0 + u + rot;
-            it = it >= niter ? it - niter : it;
-            const int t = it * 64 + lane;
-            in[u] = i0 + u < niter && t < n4;
-            const int tc = in[u] ? t : 0;
-#pragma unroll
-            for (int a = 0; a < SDM_RPW; ++a) v[u][a] = *(const f32x4*)(s[a] + 4 * tc);
-            l0[u] = *(const longlong2*)(clab + 4 * tc); l1[u] = *(const longlong2*)(clab + 4 * tc + 2);
-            cv[u] = cvalid ? *(const uint32_t*)(cvalid + 4 * tc) : 0x01010101u;
-            cv[u] = in[u] ? cv[u] : 0u;                       // a chunk outside the row counts as all-invalid
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int a = 0; a < SDM_RPW; ++a) sdm_visit4(r[a], v[u][a], cv[u], l0[u], l1[u], y[a]);
-    }
-    for (int c = (n4 << 2) + lane; c < Cn; c += 64) {
-        const bool cvd = !cvalid || cvalid[c];
-        const long l = clab[c];
-#pragma unroll
-        for (int a = 0; a < SDM_RPW; ++a) sdm_visit(r[a], s[a][c], cvd, l == y[a]);
-    }
-#pragma unroll
-    for (int a = 0; a < SDM_RPW; ++a) {
-        if (row0 + a >= R) break;                                 // wave-uniform
-        float lse = 0.f, npos = 0.f, loss = 0.f;
-        if (live[a]) {
-            npos = wave_sum(r[a].npos);
-            const float ps = wave_sum(r[a].ps);
-            const float se = wave_sum(r[a].se);
-            if (npos > 0.f) {
-                lse = logf(se);
-                loss = lse - ps / npos;
-            }
-        }
-        if (lane == 0) { stat[2 * (row0 + a)] = lse; stat[2 * (row0 + a) + 1] = npos; row_loss[row0 + a] = npos > 0.f ? loss : 0.f; }
-    }
-}
-
-// One workgroup: fixed-order sums of the per-row losses of both sides (no atomics: thousands of same-address atomics cost more
-// than the statistics pass itself, and the loss is now bit-reproducible).  acc = {sum_q2g, cnt_q2g, sum_g2q, cnt_g2q}.
-__global__ __launch_bounds__(1024) void sdm_finalize_kernel(const float* __restrict__ rstat, const float* __restrict__ cstat,
-                                                           const float* __restrict__ row_loss, int N, int Mg, float* __restrict__ acc,
-                                                           float* __restrict__ result) {
-    __shared__ float red[16][4];
-    const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = tid; r < N; r += nt)
-        if (rstat[2 * r + 1] > 0.f) { v[0] += row_loss[r]; v[1] += 1.f; }
-    for (int c = tid; c < Mg; c += nt)
-        if (cstat[2 * c + 1] > 0.f) { v[2] += row_loss[N + c]; v[3] += 1.f; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        v[k] = wave_sum(v[k]);
-        if (lane == 0) red[tid >> 6][k] = v[k];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            t[k] = 0.f;
-            for (int w = 0; w < nt / 64; ++w) t[k] += red[w][k];
-            acc[k] = t[k];
-        }
-        const float a = t[1] > 0.f ? t[0] / t[1] : 0.f;
-        const float b = t[3] > 0.f ? t[2] / t[3] : 0.f;
-        const bool any = t[1] > 0.f;
-        result[0] = any ? 0.5f * (a + b) : 0.f;
-        result[1] = any ? 1.f : 0.f;
-    }
-}
-
-// dS in place: S[i,j] <- g*0.5*[ 1[np_i>0]/cntR*(softmax_row - y/np_i) + 1[np_j>0]/cntC*(softmax_col - y/np_j) ]
-// One thread per 4 consecutive columns of one row (16-byte load + store of S; labels and the {lse, npos} pairs of the columns
-// come from L2).  HBM-bound: 8 bytes per entry.
-__device__ __forceinline__ float sdm_ds_one(float raw, bool valid, bool pos, float lse_r, float npr, float lse_c, float npc, float ir,
-                                            float ic, float half_g) {
-    if (!valid) return 0.f;
-    const float v = fminf(fmaxf(raw, -20.f), 20.f);
-    const float y = pos ? 1.f : 0.f;
-    float t = 0.f;
-    if (npr > 0.f) t += (__expf(v - lse_r) - y / npr) * ir;
-    if (npc > 0.f) t += (__expf(v - lse_c) - y / npc) * ic;
-    return (raw > -20.f && raw < 20.f) ? half_g * t : 0.f;
-}
-
-constexpr int SDM_DS_ROWS = 8;   // rows per thread: the column-side operands (labels, {lse, npos}, validity: L2) are loaded once per 8 rows
-__global__ __launch_bounds__(256) void sdm_ds_kernel(float* __restrict__ S, int ld, const int64_t* __restrict__ qlab,
-                                                     const int64_t* __restrict__ glab, const uint8_t* __restrict__ qvalid,
-                                                     const uint8_t* __restrict__ gvalid, int N, int Mg, const float* __restrict__ rstat,
-                                                     const float* __restrict__ cstat, const float* __restrict__ acc,
-                                                     const float* __restrict__ gscale) {
-    const int r0 = blockIdx.y * SDM_DS_ROWS;
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= Mg) return;
-    const bool any = acc[1] > 0.f;
-    const float ir = 1.f / acc[1], ic = acc[3] > 0.f ? 1.f / acc[3] : 0.f;    // (ir unused when acc[1] == 0: no row is live)
-    const float half_g = 0.5f * gscale[0];
-    const int nr = min(SDM_DS_ROWS, N - r0);
-    const bool full = c0 + 4 <= Mg && (ld & 3) == 0 && (((uintptr_t)S | (uintptr_t)glab | (uintptr_t)cstat) & 15) == 0;
-    if (full) {
-        const longlong2 l0 = *(const longlong2*)(glab + c0), l1 = *(const longlong2*)(glab + c0 + 2);
-        const f32x4 s0 = *(const f32x4*)(cstat + 2 * c0), s1 = *(const f32x4*)(cstat + 2 * c0 + 4);
-        const long lab[4] = {l0.x, l0.y, l1.x, l1.y};
-        const float lse_c[4] = {s0[0], s0[2], s1[0], s1[2]};
-        const float npc[4] = {ic > 0.f ? s0[1] : 0.f, ic > 0.f ? s0[3] : 0.f, ic > 0.f ? s1[1] : 0.f, ic > 0.f ? s1[3] : 0.f};
-        bool cv[4] = {true, true, true, true};
-        if (gvalid) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cv[k] = gvalid[c0 + k] != 0;
-        }
-        f32x4 v[SDM_DS_ROWS];
-#pragma unroll
-        for (int a = 0; a < SDM_DS_ROWS; ++a)
-            if (a < nr) v[a] = *(const f32x4*)(S + (size_t)(r0 + a) * ld + c0);
-#pragma unroll
-        for (int a = 0; a < SDM_DS_ROWS; ++a) {
-            if (a >= nr) break;
-            const int r = r0 + a;
-            const bool rok = (!qvalid || qvalid[r]) && any;
-            const float lse_r = rstat[2 * r], npr = rstat[2 * r + 1];
-            const long y = qlab[r];
-            f32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = sdm_ds_one(v[a][k], rok && cv[k], lab[k] == y, lse_r, npr, lse_c[k], npc[k], ir, ic, half_g);
-            *(f32x4*)(S + (size_t)r * ld + c0) = o;
-        }
-    } else {
-        for (int a = 0; a < nr; ++a) {
-            const int r = r0 + a;
-            const bool rok = (!qvalid || qvalid[r]) && any;
-            const float lse_r = rstat[2 * r], npr = rstat[2 * r + 1];
-            const long y = qlab[r];
-            float* p = S + (size_t)r * ld + c0;
-            for (int k = 0; k < 4 && c0 + k < Mg; ++k) {
-                const int c = c0 + k;
-                p[k] = sdm_ds_one(p[k], rok && (!gvalid || gvalid[c]), glab[c] == y, lse_r, npr, cstat[2 * c], ic > 0.f ? cstat[2 * c + 1] : 0.f,
-                                  ir, ic, half_g);
-            }
-        }
-    }
-}
-
 // y = x / max(||x||, eps): dx (+)= (dy - y (y.dy)) / max(||x||, eps)
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                          float* __restrict__ dx, int lddx, int rows, int D, float eps,
@@ -781,61 +576,6 @@ extern "C" int reid_ce_ls_bwd(const float* logits, int32_t ld, const int64_t* la
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, valid, rows, C, smoothing,
                        grad_scale, dlogits, lddl);
     REID_CHECK_LAUNCH("reid_ce_ls_bwd");
-    return REID_OK;
-}
-
-// workspace (floats): S[N*Mg] | ST[Mg*N] | qn[N*1024] | gn[Mg*1024] | rstat[2N] | cstat[2Mg] | acc[8] | tmp[max(N,Mg)*1024]
-static inline int64_t sdm_off_st(int N, int Mg) { return (int64_t)N * Mg; }
-extern "C" int64_t reid_sdm_ws_floats(int32_t N, int32_t Mg) {
-    return 2 * (int64_t)N * Mg + (int64_t)(N + Mg) * 1024 + 2 * (N + Mg) + 8 + (int64_t)(N > Mg ? N : Mg) * 1024;
-}
-
-extern "C" int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label, const int64_t* g_label,
-                            const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg, int32_t D, float tau, float* ws,
-                            float* result, void* stream) {
-    REID_CHECK_ARG(q && g && q_label && g_label && ws && result, "reid_sdm_fwd: null pointer");
-    REID_CHECK_ARG(N > 0 && Mg > 0 && D % 4 == 0 && D <= 1024, "reid_sdm_fwd: shape N=%d Mg=%d D=%d", N, Mg, D);
-    hipStream_t s = (hipStream_t)stream;
-    const float t = fminf(fmaxf(tau, 0.15f), 0.5f);       // models/sdm_loss.py:28
-    float* S = ws; float* ST = S + (size_t)N * Mg; float* qn = ST + (size_t)N * Mg; float* gn = qn + (size_t)N * 1024;
-    float* rstat = gn + (size_t)Mg * 1024; float* cstat = rstat + 2 * N; float* acc = cstat + 2 * Mg;
-    float* row_loss = acc + 8;                             // [N + Mg] at the start of the backward scratch region
-    int rc;
-    if ((rc = reid_l2norm_rows(q, ldq, qn, nullptr, D, N, D, 1e-8f, 1.0f, stream))) return rc;
-    if ((rc = reid_l2norm_rows(g, ldg, gn, nullptr, D, Mg, D, 1e-8f, 1.0f, stream))) return rc;
-    if ((rc = launch_sgemm(qn, gn, S, N, Mg, D, D, 1, 1, D, Mg, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
-    if ((rc = launch_sgemm(gn, qn, ST, Mg, N, D, D, 1, 1, D, N, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
-    hipLaunchKernelGGL(sdm_side_kernel, dim3((N + 4 * SDM_RPW - 1) / (4 * SDM_RPW)), dim3(256), 0, s, S, Mg, q_label, g_label, q_valid, g_valid, N, Mg, rstat, row_loss);
-    REID_CHECK_LAUNCH("reid_sdm_fwd(q2g)");
-    hipLaunchKernelGGL(sdm_side_kernel, dim3((Mg + 4 * SDM_RPW - 1) / (4 * SDM_RPW)), dim3(256), 0, s, ST, N, g_label, q_label, g_valid, q_valid, Mg, N, cstat, row_loss + N);
-    REID_CHECK_LAUNCH("reid_sdm_fwd(g2q)");
-    hipLaunchKernelGGL(sdm_finalize_kernel, dim3(1), dim3(N + Mg > 2048 ? 1024 : 256), 0, s, rstat, cstat, row_loss, N, Mg, acc, result);
-    REID_CHECK_LAUNCH("reid_sdm_fwd(finalize)");
-    return REID_OK;
-}
-
-extern "C" int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label, const int64_t* g_label,
-                            const uint8_t* q_valid, const uint8_t* g_valid, int32_t N, int32_t Mg, int32_t D, float tau, const float* ws,
-                            const float* gscale, float* dq, int32_t lddq, float* dg, int32_t lddg, void* stream) {
-    REID_CHECK_ARG(q && g && ws && gscale && dq && dg, "reid_sdm_bwd: null pointer");
-    REID_CHECK_ARG(N > 0 && N <= 65535 * SDM_DS_ROWS && Mg > 0 && D % 4 == 0 && D <= 1024, "reid_sdm_bwd: shape");
-    hipStream_t s = (hipStream_t)stream;
-    const float t = fminf(fmaxf(tau, 0.15f), 0.5f);
-    float* S = (float*)ws; float* ST = S + (size_t)N * Mg; float* qn = ST + (size_t)N * Mg; float* gn = qn + (size_t)N * 1024;
-    float* rstat = gn + (size_t)Mg * 1024; float* cstat = rstat + 2 * N; float* acc = cstat + 2 * Mg;
-    hipLaunchKernelGGL(sdm_ds_kernel, dim3((Mg + 1023) / 1024, (N + SDM_DS_ROWS - 1) / SDM_DS_ROWS), dim3(256), 0, s, S, Mg, q_label, g_label, q_valid, g_valid, N, Mg, rstat,
-                       cstat, acc, gscale);
-    REID_CHECK_LAUNCH("reid_sdm_bwd(ds)");
-    // dqn = dS . gn / tau into the scratch region [N, D], then dgn [Mg, D]
-    float* tmp = acc + 8;
-    int rc;
-    if ((rc = launch_sgemm(S, gn, tmp, N, D, Mg, Mg, 1, D, 1, D, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, q, ldq, tmp, D, dq, lddq, N, D, 1e-8f, 1);
-    REID_CHECK_LAUNCH("reid_sdm_bwd(dq)");
-    // dgn = dS^T . qn / tau : A(m=j,k=i) = S[i*Mg + j] -> sam = 1, sak = Mg
-    if ((rc = launch_sgemm(S, qn, tmp, Mg, D, N, 1, Mg, D, 1, D, 1.0f / t, 0.f, nullptr, 0, s))) return rc;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((Mg + 3) / 4), dim3(256), 0, s, g, ldg, tmp, D, dg, lddg, Mg, D, 1e-8f, 1);
-    REID_CHECK_LAUNCH("reid_sdm_bwd(dg)");
     return REID_OK;
 }
 

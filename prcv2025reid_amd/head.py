@@ -93,26 +93,31 @@ class CrossEntropyLSFn(torch.autograd.Function):
 
 
 class SDMFn(torch.autograd.Function):
-    """(loss, contributes) of sdm_loss_stable between modality features q and vis features g."""
+    """(losses [P], contributes [P]) of sdm_loss_stable between P stacked modality feature sets q [P, N, D] and the vis features
+    g [Mg, D] -- the fused kernel of csrc/sdm.hip: all pairs in one launch, no [N, Mg] matrix in memory."""
 
     @staticmethod
     def forward(ctx, q, g, q_label, g_label, q_valid, g_valid, tau: float):
-        q = q.contiguous().float(); g = g.contiguous().float()
-        ws = torch.empty(ops.sdm_ws_floats(q.shape[0], g.shape[0]), device=q.device)
-        res = torch.zeros(2, device=q.device)
-        ops.sdm_fwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, res)
-        ctx.save_for_backward(q, g, q_label, g_label, q_valid, g_valid, ws)
-        ctx.tau = tau
-        loss, flag = res[0], res[1]
+        P, N, D = q.shape
+        q2 = q.reshape(P * N, D).contiguous().float(); g = g.contiguous().float()
+        ws = torch.empty(ops.sdm_ws_floats(P, N, g.shape[0], D), device=q.device)
+        res = torch.zeros(2 * P, device=q.device)
+        qv = None if q_valid is None else q_valid.reshape(P * N).contiguous()
+        ops.sdm_fwd(q2, g, q_label, g_label, qv, g_valid, tau, ws, res, P=P)
+        ctx.save_for_backward(q2, g, q_label, g_label, qv, g_valid, ws)
+        ctx.tau, ctx.P = tau, P
+        res = res.view(P, 2)
+        loss, flag = res[:, 0].contiguous(), res[:, 1].contiguous()
         ctx.mark_non_differentiable(flag)
         return loss, flag
 
     @staticmethod
     def backward(ctx, dloss, _dflag):
-        q, g, ql, gl, qv, gv, ws = ctx.saved_tensors
-        dq = torch.zeros_like(q); dg = torch.zeros_like(g)
-        ops.sdm_bwd(q, g, ql, gl, qv, gv, ctx.tau, ws, dloss.reshape(1).float().contiguous(), dq, dg)
-        return dq, dg, None, None, None, None, None
+        q2, g, ql, gl, qv, gv, ws = ctx.saved_tensors
+        P = ctx.P
+        dq = torch.zeros_like(q2); dg = torch.zeros_like(g)
+        ops.sdm_bwd(q2, g, ql, gl, qv, gv, ctx.tau, ws, dloss.reshape(P).float().contiguous(), dq, dg, P=P)
+        return dq.view(P, q2.shape[0] // P, q2.shape[1]), dg, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------

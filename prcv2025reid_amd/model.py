@@ -583,14 +583,13 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         raw = outputs.get('raw_modality_features', {})
         if use_sdm and 'vis' in raw and 'vis' in fm:
             gv = (fm['vis'] > 0).to(torch.uint8).contiguous()
-            tot, n = zero, zero
-            for m, feat in raw.items():
-                if m == 'vis' or m not in fm:
-                    continue
-                qv = (fm[m] > 0).to(torch.uint8).contiguous()
-                L, flag = SDMFn.apply(feat, raw['vis'], labels, labels, qv, gv, float(self.sdm_temperature))
-                tot = tot + L; n = n + flag
-            sdm = tot / n.clamp_min(1.0)
+            mods = [m for m in raw if m != 'vis' and m in fm]
+            if mods:
+                # every non-vis modality against vis in ONE fused launch (csrc/sdm.hip): the query sides are stacked
+                q = torch.stack([raw[m] for m in mods], dim=0)                                   # [P, B, D]
+                qv = torch.stack([(fm[m] > 0) for m in mods], dim=0).to(torch.uint8).contiguous()
+                L, flag = SDMFn.apply(q, raw['vis'], labels, labels, qv, gv, float(self.sdm_temperature))
+                sdm = L.sum() / flag.sum().clamp_min(1.0)                                        # mean over the pairs that contribute (model.py:617-622)
         total = self.ce_weight * ce + self.contrastive_weight * sdm
         return {'total_loss': total, 'ce_loss': ce, 'sdm_loss': sdm, 'contrastive_loss': sdm, 'ce_valid_cnt': LazyCount(cnt)}
 

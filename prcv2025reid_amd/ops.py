@@ -228,18 +228,21 @@ def ce_ls_bwd(logits, labels, valid, grad_scale, dlogits, smoothing=0.1):
                                C.c_float(smoothing), ptr(grad_scale), ptr(dlogits), dlogits.stride(0), stream_ptr()))
 
 
-def sdm_ws_floats(N, Mg):
-    return int(lib().reid_sdm_ws_floats(N, Mg))
+def sdm_ws_floats(P, N, Mg, D):
+    return int(lib().reid_sdm_ws_floats(P, N, Mg, D))
 
 
-def sdm_fwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, result):
+def sdm_fwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, result, P=1):
+    """q [P*N, D] (P query sides stacked), g [Mg, D]; result f32 [2*P] = (loss, contributes) per pair."""
+    N = q.shape[0] // P
     check(lib().reid_sdm_fwd(ptr(q), q.stride(0), ptr(g), g.stride(0), ptr(q_label), ptr(g_label), ptr(q_valid), ptr(g_valid),
-                             q.shape[0], g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(result), stream_ptr()))
+                             P, N, g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(result), stream_ptr()))
 
 
-def sdm_bwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, gscale, dq, dg):
+def sdm_bwd(q, g, q_label, g_label, q_valid, g_valid, tau, ws, gscale, dq, dg, P=1):
+    N = q.shape[0] // P
     check(lib().reid_sdm_bwd(ptr(q), q.stride(0), ptr(g), g.stride(0), ptr(q_label), ptr(g_label), ptr(q_valid), ptr(g_valid),
-                             q.shape[0], g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(gscale), ptr(dq), dq.stride(0),
+                             P, N, g.shape[0], q.shape[1], C.c_float(tau), ptr(ws), ptr(gscale), ptr(dq), dq.stride(0),
                              ptr(dg), dg.stride(0), stream_ptr()))
 
 

@@ -321,29 +321,42 @@ def test_ce_label_smoothing(ops):
     assert rel_err(dl, zr.grad) < 1e-5
 
 
-@pytest.mark.parametrize('N,Mg', [(16, 48), (64, 64), (130, 70), (516, 1024)])
-def test_sdm(ops, N, Mg):
-    import sys, os
+@pytest.mark.parametrize('P,N,Mg,D', [(1, 16, 48, 512), (1, 64, 64, 512), (4, 64, 64, 512), (3, 130, 70, 512), (2, 516, 1024, 512),
+                                      (4, 200, 200, 256), (1, 1030, 650, 512)])
+def test_sdm(ops, P, N, Mg, D):
+    """Fused SDM (csrc/sdm.hip): P stacked query sides against one gallery side, vs the oracle's sdm_loss per pair
+    (1e-5 on the loss, 1e-4 relative on both gradients); rows / columns masked out; tiles of 64 and of 128."""
     from oracle import reid_oracle as O
-    g = torch.Generator(device='cuda').manual_seed(N)
-    D = 512
-    q = torch.randn(N, D, device='cuda', generator=g); gal = torch.randn(Mg, D, device='cuda', generator=g)
+    g = torch.Generator(device='cuda').manual_seed(N + 7 * P)
+    q = torch.randn(P * N, D, device='cuda', generator=g); gal = torch.randn(Mg, D, device='cuda', generator=g)
     ql = torch.randint(0, 10, (N,), device='cuda', generator=g); gl = torch.randint(0, 10, (Mg,), device='cuda', generator=g)
-    qv = (torch.rand(N, device='cuda', generator=g) > 0.2).to(torch.uint8); gv = (torch.rand(Mg, device='cuda', generator=g) > 0.2).to(torch.uint8)
-    ws = torch.empty(ops.sdm_ws_floats(N, Mg), device='cuda'); res = torch.zeros(2, device='cuda')
-    ops.sdm_fwd(q, gal, ql, gl, qv, gv, 0.2, ws, res)
+    qv = (torch.rand(P * N, device='cuda', generator=g) > 0.2).to(torch.uint8); gv = (torch.rand(Mg, device='cuda', generator=g) > 0.2).to(torch.uint8)
+    if P > 1:
+        qv[N:2 * N] = 0; qv[N] = 1; ql = ql.clone(); ql[0] = 77          # pair 1: one valid row whose label has no partner -> no positive
+        gl = gl.clone(); gl[gl == 77] = 0
+    ws = torch.empty(ops.sdm_ws_floats(P, N, Mg, D), device='cuda'); res = torch.zeros(2 * P, device='cuda')
+    ops.sdm_fwd(q, gal, ql, gl, qv, gv, 0.2, ws, res, P=P)
     qc = q.cpu().requires_grad_(True); gc = gal.cpu().requires_grad_(True)
-    qi, gi = qv.cpu().bool(), gv.cpu().bool()
-    y = (ql.cpu()[qi].view(-1, 1) == gl.cpu()[gi].view(1, -1)).float()
-    ref = O.sdm_loss(qc[qi], gc[gi], y, tau=0.2)
-    assert abs(float(res[0]) - float(ref)) < 1e-5 and float(res[1]) == 1.0
-    (ref * 1.3).backward()
-    dq = torch.zeros(N, D, device='cuda'); dg = torch.zeros(Mg, D, device='cuda')
-    ops.sdm_bwd(q, gal, ql, gl, qv, gv, 0.2, ws, torch.tensor([1.3], device='cuda'), dq, dg)
+    gi = gv.cpu().bool()
+    gs = torch.linspace(0.7, 1.3, P)
+    tot = 0.0
+    for p_ in range(P):
+        qi = qv.cpu()[p_ * N:(p_ + 1) * N].bool()
+        y = (ql.cpu()[qi].view(-1, 1) == gl.cpu()[gi].view(1, -1)).float()
+        ref = O.sdm_loss(qc[p_ * N:(p_ + 1) * N][qi], gc[gi], y, tau=0.2)
+        contributes = float(y.sum()) > 0
+        assert abs(float(res[2 * p_]) - float(ref)) < 1e-5, (p_, float(res[2 * p_]), float(ref))
+        assert float(res[2 * p_ + 1]) == (1.0 if contributes else 0.0)
+        tot = tot + ref * gs[p_]
+    tot.backward()
+    dq = torch.zeros(P * N, D, device='cuda'); dg = torch.zeros(Mg, D, device='cuda')
+    ops.sdm_bwd(q, gal, ql, gl, qv, gv, 0.2, ws, gs.cuda(), dq, dg, P=P)
     assert rel_err(dq.cpu(), qc.grad) < 1e-4 and rel_err(dg.cpu(), gc.grad) < 1e-4
+    assert float(dq[(qv == 0)].abs().max()) == 0.0                        # masked rows get no gradient
     # no positives at all -> 0 and "does not contribute"
-    ops.sdm_fwd(q, gal, ql, gl + 100, qv, gv, 0.2, ws, res)
-    assert float(res[0]) == 0.0 and float(res[1]) == 0.0
+    ops.sdm_fwd(q, gal, ql, gl + 100, qv, gv, 0.2, ws, res, P=P)
+    assert float(res.abs().max()) == 0.0
+    assert ops.sdm_ws_floats(1, 8192, 8192, 512) < 3 * (8192 + 8192) * 512          # O((N + M) D): no N x M term
 
 
 @pytest.mark.parametrize('Nq,Ng,k', [(64, 4096, 10), (200, 20000, 10), (33, 777, 100), (130, 5000, 1)])
