@@ -168,6 +168,10 @@ int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table,
 /* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */
 int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd,
                          int32_t rows, int32_t cols, void* stream);
+/* Text-tower input (HF CLIPTextEmbeddings, models/clip_backbone.py:307): out[b*T + t, :] = tok[ids[b, t], :] + pos[t, :]
+ * (f32 tables [vocab, D] / [>= T, D], ids int64 [B, T]; ids outside the vocabulary are clamped). */
+int reid_embed_tokens(const float* tok, const float* pos, const int64_t* ids, float* out, int32_t B, int32_t T, int32_t D,
+                      int32_t vocab, void* stream);
 /* out[index[r], :] += src[r, :] (f32; rows with an index outside [0, out_rows) are skipped): gradient of an embedding
  * lookup (HF CLIPTextEmbeddings.token_embedding) when the text tower trains. */
 int reid_scatter_add_rows_f32(const float* src, int32_t lds, const int32_t* index, float* out, int32_t ldo,

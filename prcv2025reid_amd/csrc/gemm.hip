@@ -305,6 +305,12 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
     // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip; r01: a three-buffer ring
     //  with counted vmcnt -- twice the bytes in flight per workgroup -- changed the step time by < 0.1 %: not kept)
+    // (r02: a streaming form of these projections -- activation fragments loaded straight into VGPRs, 24 KiB per wave in flight,
+    //  the small weight fragment-linear in LDS -- was built and measured against this tiled form on the three LoRA shapes,
+    //  bit-identical outputs: 26 / 93 / 26 us vs 16 / 58 / 16 us stand-alone.  Fragment-shaped global
+    //  loads (16 rows x 64 bytes per instruction) cost the vector-memory path more than the LDS round trip saves; stand-alone
+    //  the tiled form already streams at 4.9-5.4 TB/s -- the 31 us seen in the train step is interference from the dA/dB
+    //  reductions on the side stream, not this kernel.)
     if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
     if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);

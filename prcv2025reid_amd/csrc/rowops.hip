@@ -407,6 +407,29 @@ extern "C" int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t
     return REID_OK;
 }
 
+namespace {
+// x[b*T + t, :] = tok[ids[b, t], :] + pos[t, :]   (HF CLIPTextEmbeddings, clip_backbone.py:307): one 16-byte piece per thread
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ pos, const int64_t* __restrict__ ids,
+                                                          float* __restrict__ out, int rows, int T, int D, int vocab) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per = D >> 2;
+    if (t >= (long)rows * per) return;
+    const int r = (int)(t / per), c = (int)(t - (long)r * per) * 4;
+    long id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f32x4 a = *(const f32x4*)(tok + (size_t)id * D + c), b = *(const f32x4*)(pos + (size_t)(r % T) * D + c);
+    *(f32x4*)(out + (size_t)r * D + c) = a + b;
+}
+}  // namespace
+extern "C" int reid_embed_tokens(const float* tok, const float* pos, const int64_t* ids, float* out, int32_t B, int32_t T, int32_t D,
+                                 int32_t vocab, void* stream) {
+    REID_CHECK_ARG(tok && pos && ids && out && B > 0 && T > 0 && D > 0 && D % 4 == 0 && vocab > 0, "reid_embed_tokens: bad args");
+    const long n = (long)B * T * (D / 4);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok, pos, ids, out, B * T, T, D, vocab);
+    REID_CHECK_LAUNCH("reid_embed_tokens");
+    return REID_OK;
+}
+
 extern "C" int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t D,
                                 float eps, float scale, void* stream) {
     REID_CHECK_ARG(x && (y || y_bf16) && rows > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "reid_l2norm_rows: bad args");

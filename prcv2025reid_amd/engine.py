@@ -533,10 +533,10 @@ class Engine:
         B, T = input_ids.shape
         td, tff, heads = a['text_hidden_dim'], a['text_mlp_dim'], a['text_heads']
         f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=_lib.t16(), device=dev)
-        ids = input_ids.to(dev)
-        # embedding lookup is a gather (plumbing); the add is one fused epilogue-free op on [B*T, td]
-        x = (P[tp + 'embeddings.token_embedding.weight'].detach()[ids] +
-             P[tp + 'embeddings.position_embedding.weight'].detach()[:T].unsqueeze(0)).reshape(B * T, td).contiguous()
+        ids = input_ids.to(dev).long().contiguous()
+        x = torch.empty(B * T, td, **f32)
+        ops.embed_tokens(P[tp + 'embeddings.token_embedding.weight'].detach(), P[tp + 'embeddings.position_embedding.weight'].detach(),
+                         ids, x)
         km = None
         if attention_mask is not None:
             km = attention_mask.to(dev).to(torch.uint8).contiguous()

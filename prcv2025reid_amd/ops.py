@@ -310,3 +310,10 @@ def scatter_add_rows(src, index, out):
     """out[index[r]] += src[r] (f32 rows; int32 index)."""
     check(lib().reid_scatter_add_rows_f32(ptr(src), src.stride(0), ptr(index), ptr(out), out.stride(0), src.shape[0], src.shape[1],
                                           out.shape[0], stream_ptr()))
+
+
+def embed_tokens(tok, pos, ids, out):
+    """out[b*T + t] = tok[ids[b, t]] + pos[t]  (text-tower input, f32)."""
+    B, T = ids.shape
+    check(lib().reid_embed_tokens(ptr(tok), ptr(pos), ptr(ids), ptr(out), B, T, tok.shape[1], tok.shape[0], stream_ptr()))
+    return out
