@@ -52,7 +52,8 @@ struct Geo {
     static constexpr int DS_LD = TS + 1;                            // padded dS row (floats)
     static constexpr int LDS_SIDE = 8 * TS * 4 + 2 * TS * 8;        // row / column scratch {3 floats x 2 waves}, labels
     static constexpr int LDS_FWD = LDS_STAGE > LDS_SIDE ? LDS_STAGE : LDS_SIDE;
-    static constexpr int LDS_BWD = LDS_STAGE + TS * DS_LD * 4;
+    static constexpr int DS_BYTES = TS * DS_LD * 4;                  // the dS tile takes over the staging area after the K loop
+    static constexpr int LDS_BWD = (DS_BYTES > LDS_STAGE ? DS_BYTES : LDS_STAGE) + 32 * TS;
 };
 
 // S tile: acc[a][b][reg] = q^[m] . g^[n],  m = wm*WT + 32a + (reg&3) + 8(reg>>2) + 4(lane>>5),  n = wn*WT + 32b + (lane&31)
@@ -129,7 +130,7 @@ __device__ __forceinline__ void tile_of(const SdmParams& p, int& pair, int& tm, 
 }
 
 template <int TS>
-__global__ __launch_bounds__(256) void sdm_fwd_tile_kernel(const SdmParams p) {
+__global__ __launch_bounds__(256, 2) void sdm_fwd_tile_kernel(const SdmParams p) {
     using G = Geo<TS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -161,48 +162,51 @@ __global__ __launch_bounds__(256) void sdm_fwd_tile_kernel(const SdmParams p) {
     }
     __syncthreads();
     const int j = lane & 31, h = lane >> 5;
-    float rs[G::NT32][16][3];                           // row sums over this wave's columns (after the butterflies)
-#pragma unroll
-    for (int a = 0; a < G::NT32; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[a][r][0] = rs[a][r][1] = rs[a][r][2] = 0.f;
+    // Per accumulator row: this lane's elements (one per column tile b) are summed, the 32 lanes of the half-wave are
+    // combined by an xor butterfly at once (nothing but the six column sums stays live across rows: the kernel keeps to
+    // 2 waves per SIMD, i.e. two workgroups per CU, which the barrier-synchronised K loop needs to keep the MFMA pipe busy).
+    float cs[G::NT32][3];
+    bool gv[G::NT32]; int64_t gl[G::NT32];
 #pragma unroll
     for (int b = 0; b < G::NT32; ++b) {
         const int nl = wn * G::WT + 32 * b + j;
-        const bool gv = l_gv[nl] != 0;
-        const int64_t gl = l_gl[nl];
-        float cs[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int a = 0; a < G::NT32; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * G::WT + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool ok = gv && l_qv[ml] != 0;
-                const float v = fminf(fmaxf(acc[a][b][r] * p.inv_tau, -20.f), 20.f);       // models/sdm_loss.py:94
-                const float e = ok ? __expf(v) : 0.f;
-                const bool pos = ok && l_ql[ml] == gl;
-                const float pv = pos ? v : 0.f, pc = pos ? 1.f : 0.f;
-                cs[0] += e; cs[1] += pv; cs[2] += pc;
-                rs[a][r][0] += e; rs[a][r][1] += pv; rs[a][r][2] += pc;
-            }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) cs[q] += __shfl_xor(cs[q], 32, 64);                  // both halves: all 32 rows of the a-tiles
-        if (h == 0) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) l_col[(wm * TS + nl) * 4 + q] = cs[q];
-        }
+        gv[b] = l_gv[nl] != 0; gl[b] = l_gl[nl];
+        cs[b][0] = cs[b][1] = cs[b][2] = 0.f;
     }
 #pragma unroll
     for (int a = 0; a < G::NT32; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = wm * G::WT + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool qv = l_qv[ml] != 0;
+            const int64_t ql = l_ql[ml];
+            float rs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < G::NT32; ++b) {
+                const bool ok = gv[b] && qv;
+                const float v = fminf(fmaxf(acc[a][b][r] * p.inv_tau, -20.f), 20.f);       // models/sdm_loss.py:94
+                const float e = ok ? __expf(v) : 0.f;
+                const bool pos = ok && ql == gl[b];
+                const float pv = pos ? v : 0.f, pc = pos ? 1.f : 0.f;
+                cs[b][0] += e; cs[b][1] += pv; cs[b][2] += pc;
+                rs[0] += e; rs[1] += pv; rs[2] += pc;
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const float t = half_sum(rs[a][r][q]);
+                const float t = half_sum(rs[q]);
                 if (j == 0) l_row[(wn * TS + ml) * 4 + q] = t;
             }
         }
+#pragma unroll
+    for (int b = 0; b < G::NT32; ++b) {
+        const int nl = wn * G::WT + 32 * b + j;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cs[b][q] += __shfl_xor(cs[b][q], 32, 64);            // both halves: all rows of the a-tiles
+        if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) l_col[(wm * TS + nl) * 4 + q] = cs[b][q];
+        }
+    }
     __syncthreads();
     if (tid < TS) {
         const int m = m0 + tid;
@@ -322,7 +326,7 @@ __device__ __forceinline__ void ds_times(const float* __restrict__ ds, const flo
 }
 
 template <int TS>
-__global__ __launch_bounds__(256) void sdm_bwd_tile_kernel(const SdmParams p) {
+__global__ __launch_bounds__(256, TS == 128 ? 1 : 2) void sdm_bwd_tile_kernel(const SdmParams p) {      // (128: 2 waves/SIMD would spill)
     using G = Geo<TS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -336,10 +340,10 @@ __global__ __launch_bounds__(256) void sdm_bwd_tile_kernel(const SdmParams p) {
     f32x16_t acc[G::NT32][G::NT32];
     s_tile<TS>(p, row_lo, row_lo + p.N - 1, m0, n0, smem, acc);
 
-    int64_t* l_ql = (int64_t*)smem; int64_t* l_gl = l_ql + TS;
+    float* ds = (float*)smem;                           // [TS][TS + 1], over the (idle) staging buffers
+    int64_t* l_ql = (int64_t*)(smem + G::LDS_BWD - 32 * TS); int64_t* l_gl = l_ql + TS;
     float* l_rs = (float*)(l_gl + TS);                  // [TS][2] {lse, #pos} of the rows; #pos < 0 marks an invalid row
     float* l_cs = l_rs + 2 * TS;                        // [TS][2] of the columns
-    float* ds = (float*)(smem + G::LDS_STAGE);          // [TS][TS + 1]
     if (tid < TS) {
         const int m = m0 + tid;
         const bool ok = m < p.N && (!p.qvalid || p.qvalid[row_lo + m]);
