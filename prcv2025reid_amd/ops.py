@@ -65,7 +65,15 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         e1.record()
         kk = a.K + a.K2
         flops = 2.0 * a.M * a.N * kk
+        # compulsory bytes of the launch: both operands once, C once, plus every epilogue operand it must read or write
+        # (residual R, saved pre-activation aux, second output C2) -- r01 left the last three out and overstated traffic / algorithmic
         nbytes = 2.0 * (a.M * kk + a.N * kk) + a.M * a.N * (2 if a.c_dtype == BF16 else 4)
+        if R is not None:
+            nbytes += (r_period if r_period > 0 else a.M) * a.N * (2 if a.r_dtype == BF16 else 4)
+        if aux is not None:
+            nbytes += a.M * a.N * 2
+        if C2 is not None:
+            nbytes += a.M * a.N * (2 if a.c2_dtype == BF16 else 4)
         _gemm_profile.append((flops, nbytes, e0, e1))
         return C_out
     check(lib().reid_mer_gemm(C.byref(a), stream_ptr()))
