@@ -16,7 +16,7 @@ identities).  N > 1: configs[2] (P=32, K=4 PER GPU, same model; weak scaling), a
 value of that same per-GPU workload measured on rank 0 alone (`n1_same_workload`).  Inputs are resident in HBM.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mer_gemm_kernel<128,128,2,2>, bf16 MFMA): algorithmic FLOPs of every launch in
+  roofline      -- dominant kernel (the MER GEMM: mer_gemm_pp_kernel / mer_gemm_kernel<128,128,2,2>, bf16 MFMA): algorithmic FLOPs of every launch in
                    the timed region / its duration measured with HIP events on the launch stream
   flavors       -- step time of BOTH 16-bit operand flavors (bf16 = headline, f16) on the same workload
   parity        -- per flavor, HIP vs the CPU oracle on the full-size batch of this workload (regularisers off): per-modality
@@ -72,17 +72,19 @@ def parse():
 PMC_FILE = 'r02_pmc_traffic.json'
 
 
-def pmc_traffic(*kernels):
-    """Launch-weighted HBM bytes per launch of `kernels` from the committed PMC summary (collected with separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide prescribes)."""
+def pmc_traffic(*prefixes):
+    """Launch-weighted HBM bytes per launch of the kernels whose name starts with one of `prefixes`, from the committed PMC summary
+    (collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide
+    prescribes)."""
     path = os.path.join(ROOT, 'profiles', PMC_FILE)
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    n = sum(d[k]['launches'] for k in kernels if k in d)
+    ks = [k for k in d if any(k.startswith(p) for p in prefixes)]
+    n = sum(d[k]['launches'] for k in ks)
     if n == 0:
         return None
-    return sum(d[k]['traffic_bytes_per_launch'] * d[k]['launches'] for k in kernels if k in d) / n
+    return sum(d[k]['traffic_bytes_per_launch'] * d[k]['launches'] for k in ks) / n
 
 
 def cpu_baseline():
@@ -474,8 +476,9 @@ def main():
     if prof:
         fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
-        res['roofline'] = {'kernel': 'mer_gemm_kernel<128,128,2,2>', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_kernel<128, 128, 2, 2>'),
+        res['roofline'] = {'kernel': 'mer_gemm_pp_kernel<EPI> (256x256 ping-pong tile) + mer_gemm_kernel<128,128,2,2,EPI> (the same MER GEMM; tile chosen per shape)',
+                           'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_pp_kernel', 'mer_gemm_kernel<128, 128, 2, 2'),
                            'traffic_note': f'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/{PMC_FILE}); null if not collected',
                            'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
                            'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
@@ -484,7 +487,7 @@ def main():
         nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
         gbs = nb / (ms * 1e-3) / 1e9
         res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                               'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true, false>') or pmc_traffic('ln_bwd_kernel<true>'), 'launches': len(ln_prof),
+                               'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true'), 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
     if world > 1:

@@ -35,7 +35,15 @@ struct GemmParams {
     int group_m;  // row tiles per L2 group of the tile order (gemm_core.h tile_coords)
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
+    int epi;      // EPI_*: which epilogue the kernel instance was built with (host side choice)
 };
+
+// Epilogue kinds.  The GENERIC epilogue evaluates every option of reid_mer_gemm at run time (~100-600 instructions per 16-byte
+// piece, ~1 000 scalar branches in the kernel): it is instruction-issue bound and held the C / residual traffic of the big GEMMs at
+// 3-4 TB/s where plain 16-byte stores of the same shape reach 7 TB/s (r02: tools/store_patterns.hip, REID_GEMM_DBG=4).  The four
+// kinds below cover the seven ViT GEMM variants of a training step with straight-line code (32-bit offsets, one predicate per
+// row, no option tests); everything else (patch embed row remap, routing masks, alpha, quick-GELU, ...) stays on GENERIC.
+enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4 };
 
 using namespace gemmcore;
 
@@ -198,6 +206,84 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
     }
 }
 
+// Lean epilogues (host side guarantees: N a multiple of the tile, every stride a multiple of 8 elements, every operand below
+// 4 GiB, alpha == 1, no mask / row remap / periodic residual).  Layout as in store_tile_m: the 16-bit kinds use the perm32
+// weight-row staging (a lane owns 8 consecutive columns per pair of MFMA sub-tiles), EPI_RES32 the natural one (4 columns).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    if constexpr (EPI == EPI_RES32) {
+        const uint32_t col = (uint32_t)(n_base + 4 * fq);
+        char* C = (char*)p.C; const char* R = (const char*)p.R;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + 16 * i + frow;
+            const bool ok = m < p.M;
+            const int mc = ok ? m : p.M - 1;
+            const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 4u, ro = ((uint32_t)mc * (uint32_t)p.ldr + col) * 4u;
+            f32x4 r[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) r[j] = *(const f32x4*)(R + ro + 64u * j);
+            float rs = 1.f;
+            if (p.row_scale) rs = p.row_scale[mc / p.rows_per_img];               // DropPath: the branch output of this sample
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 v = acc[j][i] * rs + r[j];
+                if (ok) *(f32x4*)(C + co + 64u * j) = v;
+            }
+        }
+    } else {
+        constexpr int NP = TN / 2;                                                   // 8-column pieces per 16-row group
+        const uint32_t col = (uint32_t)(n_base + 8 * fq);
+        char* C = (char*)p.C;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + 16 * i + frow;
+            const bool ok = m < p.M;
+            const int mc = ok ? m : p.M - 1;
+            const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 2u;
+            bf16x8 av[NP];
+            if constexpr (EPI == EPI_DGELU) {
+                const uint32_t ao = ((uint32_t)mc * (uint32_t)p.ldaux + col) * 2u;
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) av[pc] = *(const bf16x8*)((const char*)p.aux + ao + 64u * pc);
+            }
+            const uint32_t c2o = EPI == EPI_GELU2 ? ((uint32_t)mc * (uint32_t)p.ldc2 + col) * 2u : 0u;
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[2 * pc + (e >> 2)][i][e & 3];
+                if constexpr (EPI == EPI_GELU2) {
+                    if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[pc][e]));
+                }
+                if (ok) *(uint4*)(C + co + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            }
+        }
+    }
+}
+
+// host side: which lean epilogue (if any) covers this launch
+static int pick_epilogue(const GemmParams& p, int BN) {
+    if (p.alpha != 1.f || p.mask_r > 0 || p.c_group > 0 || p.r_period > 0 || p.N % BN != 0) return EPI_GENERIC;
+    const long mx = (long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr);
+    if (mx * 4 >= (1L << 32) || (long)p.M * p.ldaux * 2 >= (1L << 32) || (long)p.M * p.ldc2 * 2 >= (1L << 32)) return EPI_GENERIC;
+    if (p.c_dtype == REID_F32) {
+        if (p.R && p.r_dtype == REID_F32 && !p.C2 && !p.aux && p.act == REID_ACT_NONE && (p.ldc & 3) == 0 && (p.ldr & 3) == 0) return EPI_RES32;
+        return EPI_GENERIC;
+    }
+    if (!p.perm_b || p.R || p.row_scale) return EPI_GENERIC;
+    if (p.act == REID_ACT_NONE && !p.C2 && !p.aux) return EPI_PLAIN16;
+    if (p.act == REID_ACT_GELU_ERF && p.C2 && p.c2_dtype != REID_F32 && !p.aux) return EPI_GELU2;
+    if (p.act == REID_ACT_DGELU_ERF && p.aux && !p.C2) return EPI_DGELU;
+    return EPI_GENERIC;
+}
+
 // 16-byte pieces need 16-byte aligned rows in every epilogue operand; perm_b (host side) must match the MODE chosen here
 __host__ __device__ inline bool epilogue_wide16(const GemmParams& p) {
     return p.c_dtype != REID_F32 && ((p.N | p.ldc) & 7) == 0 && (!p.C2 || (p.ldc2 & 7) == 0) && (!p.R || (p.ldr & 7) == 0) &&
@@ -211,7 +297,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
     else store_tile_m<TM, TN, 2>(p, acc, m_base, n_base, lane);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmParams p) {
     using C = Cfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,14 +315,94 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
 
     f32x4 acc[C::TN][C::TM];
-    init_acc<C::TM, C::TN>(p, acc, n0 + wn * (BN / WN), lane);
+    if constexpr (EPI == EPI_GENERIC) init_acc<C::TM, C::TN>(p, acc, n0 + wn * (BN / WN), lane);
+    else if constexpr (EPI == EPI_RES32) init_acc_m<C::TM, C::TN, 0>(p, acc, n0 + wn * (BN / WN), lane);
+    else init_acc_m<C::TM, C::TN, 1>(p, acc, n0 + wn * (BN / WN), lane);
     if (p.dbg != 4)
         mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
                                  p.perm_b != 0);
 
     // ------------------------------------------------------------------ epilogue (registers -> global, no LDS)
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    if (p.dbg != 1) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    if (p.dbg == 1) return;
+    if constexpr (EPI == EPI_GENERIC) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else store_tile_fast<C::TM, C::TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// 256 x 256 tile with the wave-row ping-pong K loop of gemm_core.h (mainloop_pp); epilogue = the same register-direct code
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
+    const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
+    f32x4 acc[4][8];
+    if constexpr (EPI == EPI_GENERIC) init_acc<8, 4>(p, acc, n0 + wn * 64, lane);
+    else if constexpr (EPI == EPI_RES32) init_acc_m<8, 4, 0>(p, acc, n0 + wn * 64, lane);
+    else init_acc_m<8, 4, 1>(p, acc, n0 + wn * 64, lane);
+    if (p.dbg != 4)
+        mainloop_pp<256, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
+    if (p.dbg == 1) return;
+    if constexpr (EPI == EPI_GENERIC) store_tile<8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    else store_tile_fast<8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+template <int EPI>
+int launch_pp_e(GemmParams& p, hipStream_t s) {
+    using C = PPCfg<256, 256>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mer_gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mer_gemm_pp_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    REID_CHECK_LAUNCH("reid_mer_gemm");
+    return REID_OK;
+}
+int launch_pp(GemmParams& p, hipStream_t s) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 256);
+    switch (p.epi) {
+        case EPI_PLAIN16: return launch_pp_e<EPI_PLAIN16>(p, s);
+        case EPI_RES32: return launch_pp_e<EPI_RES32>(p, s);
+        case EPI_GELU2: return launch_pp_e<EPI_GELU2>(p, s);
+        case EPI_DGELU: return launch_pp_e<EPI_DGELU>(p, s);
+        default: return launch_pp_e<EPI_GENERIC>(p, s);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_e(GemmParams& p, hipStream_t s) {
+    using C = Cfg<BM, BN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mer_gemm_kernel<BM, BN, WM, WN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mer_gemm_kernel<BM, BN, WM, WN, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    REID_CHECK_LAUNCH("reid_mer_gemm");
+    return REID_OK;
+}
+// the default 128 x 128 tile with the lean epilogue that covers the launch (GENERIC otherwise)
+int launch_main(GemmParams& p, hipStream_t s) {
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 127) / 128;
+    p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 128);
+    switch (p.epi) {
+        case EPI_PLAIN16: return launch_e<128, 128, 2, 2, EPI_PLAIN16>(p, s);
+        case EPI_RES32: return launch_e<128, 128, 2, 2, EPI_RES32>(p, s);
+        case EPI_GELU2: return launch_e<128, 128, 2, 2, EPI_GELU2>(p, s);
+        case EPI_DGELU: return launch_e<128, 128, 2, 2, EPI_DGELU>(p, s);
+        default: return launch_e<128, 128, 2, 2, EPI_GENERIC>(p, s);
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -318,8 +484,19 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     const int tile = reid_knob(KNOB_GEMM_TILE) > 0 ? reid_knob(KNOB_GEMM_TILE) : 0;
     p.dbg = reid_knob(KNOB_GEMM_DBG) > 0 ? reid_knob(KNOB_GEMM_DBG) : 0;
     if (tile == 2) return launch<256, 256, 2, 4>(p, s);
-    if (tile == 3) return launch<128, 128, 2, 2>(p, s);
+    if (tile == 3) return launch_main(p, s);
     if (tile == 8) return launch<128, 256, 2, 4>(p, s);
+    {
+        // 256 x 256 ping-pong tile (gemm_core.h mainloop_pp) where it wins (r02, same harness, sum of the seven ViT shapes: 1.74 ms vs
+        // 1.89 ms for the 128 x 128 tile, both with the lean epilogues; with the GENERIC epilogue it loses, 2.16 ms): every shape
+        // except the short-K, narrow-N out-projection (591 tiles of 256 x 256 = 2.3 waves of the chip and only 12 K-tiles each),
+        // and only when a lean epilogue covers the launch and there is at least one tile per CU.
+        const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
+        const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();
+        if (pp_ok && (tile == 12 || (tile == 0 && pp_shape && reid_knob(KNOB_GEMM_EPI) != 0 && pick_epilogue(p, 256) != EPI_GENERIC)))
+            return launch_pp(p, s);
+    }
     // Default from same-process A/B runs of the seven ViT GEMM variants (tools/bench_gemm_variants.py, r01): 128x128x64
     // tiles, 4 waves, 64 KiB of LDS -> TWO workgroups per CU.  With the register-direct epilogue its K loop runs as fast
     // as the 256x256 tile's (~1.0-1.1 PF on these shapes) and, unlike one big workgroup per CU, one workgroup's stores
@@ -346,5 +523,5 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     // waves of 64x128, 128x128 with 2/3/4 stages at 2/3/4 workgroups per CU): 5-25 % slower than this on every shape;
     // a DPP lane exchange that makes the epilogue store 128 contiguous bytes per row: slower (the DPP hazards cost more
     // than the wider segments give).
-    return launch<128, 128, 2, 2>(p, s);
+    return launch_main(p, s);
 }

@@ -19,7 +19,7 @@ extern "C" int reid_version(void) { return 200; }
 
 // ---------------------------------------------------------------- experiment knobs (common.h)
 static const char* const g_knob_names[KNOB_COUNT] = {
-    "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM",
+    "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM", "GEMM_EPI",
     "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "SDM_IMPL"};
 static int g_knobs[KNOB_COUNT];
 static int* knob_table() {
