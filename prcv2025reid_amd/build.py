@@ -16,7 +16,7 @@ LIB = os.path.join(CSRC, 'libreid_hip.so')            # bf16 operands
 LIB_F16 = os.path.join(CSRC, 'libreid_hip_f16.so')    # IEEE f16 operands (same sources, -DREID_FLAVOR_F16)
 FLAVORS = (('bf16', LIB, []), ('f16', LIB_F16, ['-DREID_FLAVOR_F16']))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-value']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-value'] + os.environ.get('REID_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def sources():

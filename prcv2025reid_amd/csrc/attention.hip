@@ -120,6 +120,7 @@ struct AttnParams {
     int n_seq, S, heads, causal;
     int q_tiles;  // > 0: only the first q_tiles 32-row QUERY tiles of every sequence are computed (all keys still take part)
     int dbg;     // timing experiments (REID_ATTN_DBG): 1 = no output stores, 2 = also no softmax / P.V, 3 = staging only
+    int stagger, split;
 };
 
 // A 32x32 MFMA result tile holds, for the row on lanes l and l+32, the two 4-element halves of every 8-element column
@@ -154,19 +155,34 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
     const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+    if (p.stagger > 0 && blockIdx.x < 512) {
+        // second workgroup slot of the CU (non-zero LDS base, HW_REG_LDS_ALLOC): start it late, once
+        const uint32_t ldsa = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));
+        const bool second = p.stagger >= 100 ? (blockIdx.x & 1) : ((ldsa & 0xfff) != 0);
+        const int n = p.stagger >= 100 ? p.stagger - 100 : p.stagger;
+        if (second) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);
-    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
-
     const int q0 = wave * 32;
     const int qi = q0 + (lane & 31);
     const int qrow = qi < p.S ? qi : p.S - 1;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = gfrag(qb, p.ld, qrow, 2 * ks, lane);
-    __syncthreads();
-    if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) return;   // wave-uniform; no barrier follows
+    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
+    const bool split = TWO_PASS && p.split;
+    if (split) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // K and the Q fragments; the 4 V instructions stay in flight
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
+    if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) {             // wave-uniform
+        if (split) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        return;
+    }
 
-    if (p.dbg == 3) return;
+    if (p.dbg == 3 && !split) return;
     const FragOff fo = make_frag_off(lane);
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     const int h4 = 4 * (lane >> 5);
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (mx == -INFINITY) mx = 0.f;
         const float nmc = -mx * c;
+        if (split) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // V has landed
 #pragma unroll 1
         for (int kt = 0; kt < (p.dbg == 2 ? 0 : NT); ++kt) {
             f32x16 t = score_tile(kt);
@@ -539,8 +556,10 @@ extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     int rc = check_common("reid_attn_fwd", qkv, ld, n_seq, S, heads);
     if (rc) return rc;
     REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
-    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0};
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0, 0, 0};
     if (reid_knob(KNOB_ATTN_DBG) > 0) p.dbg = reid_knob(KNOB_ATTN_DBG);
+    if (reid_knob(KNOB_ATTN_STAGGER) > 0) p.stagger = reid_knob(KNOB_ATTN_STAGGER);
+    if (reid_knob(KNOB_ATTN_SPLIT) > 0) p.split = 1;
     DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
 }
 
@@ -552,6 +571,6 @@ extern "C" int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     REID_CHECK_ARG(out && dout && lse && dqkv && delta_ws, "reid_attn_bwd: null pointer");
     REID_CHECK_ARG(ldo >= heads * 64 && ldo % 8 == 0 && lddqkv >= 3 * heads * 64 && lddqkv % 4 == 0, "reid_attn_bwd: ldo/lddqkv");
     AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, (float*)lse, (const bf16_t*)dout, (bf16_t*)dqkv, lddqkv,
-                 delta_ws, n_seq, S, heads, causal, q_tiles, 0};
+                 delta_ws, n_seq, S, heads, causal, q_tiles, 0, 0, 0};
     DISPATCH_NT((S + 31) / 32, launch_bwd, p, (hipStream_t)stream)
 }

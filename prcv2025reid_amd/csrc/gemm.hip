@@ -347,6 +347,20 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     if constexpr (EPI == EPI_GENERIC) init_acc<8, 4>(p, acc, n0 + wn * 64, lane);
     else if constexpr (EPI == EPI_RES32) init_acc_m<8, 4, 0>(p, acc, n0 + wn * 64, lane);
     else init_acc_m<8, 4, 1>(p, acc, n0 + wn * 64, lane);
+#ifdef REID_GEMM_ABLATIONS                                  // K-loop anatomy builds (profiles/r02_gemm_variants10*.log); not in the shipped library
+    if (EPI == EPI_PLAIN16 && p.dbg >= 16) {
+        switch (p.dbg - 16) {
+            case 1: mainloop_pp<256, 256, 1>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 2: mainloop_pp<256, 256, 2>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 3: mainloop_pp<256, 256, 3>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 4: mainloop_pp<256, 256, 4>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 6: mainloop_pp<256, 256, 6>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 11: mainloop_pp<256, 256, 11>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            default: break;
+        }
+        if (acc[0][0][0] != 1234.5f) return;
+    }
+#endif
     if (p.dbg != 4)
         mainloop_pp<256, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
     if (p.dbg == 1) return;
@@ -491,6 +505,11 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         // 1.89 ms for the 128 x 128 tile, both with the lean epilogues; with the GENERIC epilogue it loses, 2.16 ms): every shape
         // except the short-K, narrow-N out-projection (591 tiles of 256 x 256 = 2.3 waves of the chip and only 12 K-tiles each),
         // and only when a lean epilogue covers the launch and there is at least one tile per CU.
+        // (r02, measured and dropped, profiles/r02_gemm_experiments2_persistent_stream.patch: a PERSISTENT form of this kernel whose
+        // half-tile prefetch runs on across output tiles, so a tile's first operands are in LDS when its loop starts -- 1804 us vs
+        // 1667 us per layer.  gfx9 counts loads and stores in one in-order vmcnt: the first counted wait of the next tile has to
+        // drain the previous tile's C stores, whereas a workgroup that simply ENDS leaves its stores draining under the next
+        // workgroup's K loop.  One tile per workgroup already has the store / K-loop overlap the persistent form was after.)
         const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
         const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
         const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();

@@ -181,20 +181,24 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
 // Why: the 128 x 128 K loop moves 15.6 KB of operands per MFLOP through the CU's vector-memory path and is bound by it
 // (71 GB/s per CU, gemm.hip); a 256 x 256 tile moves half of that.  One 8-wave workgroup per CU runs every wave in lockstep
 // if all of them do "read fragments, then MFMA" between the same two barriers, so the matrix pipe idles during the reads.
-// Here each K-tile is cut into four phases of 16 MFMAs (one quadrant of the wave's 128 x 64 output), every phase is
-//     L: ds_read the fragments the quadrant needs, issue one half-tile (16 KiB) of LDS-DMA prefetch, wait for the reads | barrier
-//     M: 16 MFMAs                                                                                                     | barrier
+// Here each K-tile is cut into two phases of 32 MFMAs (one 64-row half of the wave's 128 x 64 output each), every phase is
+//     L: ds_read the fragments the phase needs, issue LDS-DMA prefetch, wait for the reads                            | barrier
+//     M: 32 MFMAs (512 matrix-pipe cycles: longer than the partner's 16 fragment reads plus their latency)             | barrier
 // and wave row 1 runs ONE BARRIER BEHIND wave row 0 (an extra s_barrier up front): while one row's waves are in M the other
 // row's waves (their partners on the same SIMDs) are in L.  Waves w and w+4 share a SIMD.
 //
 // LDS (128 KiB): two K-tile buffers x {SA0, SA1, SB0, SB1} half-tiles of 128 rows x 128 B.  A wave reads activation rows only
-// from SA[its row] and weight rows only from SB[its column pair]; SB is fully read after phase 1, SA after phase 2, so during
-// K-tile T:  p0 stages SA1(T+1), p1 SB1(T+1) into the OTHER buffer (their last readers finished in tile T-1) and p2 stages
-// SB0(T+2), p3 SA0(T+2) into THIS buffer.  A slot read in phase p is refilled in phase p+1 or later: every L ends with
-// lgkmcnt(0) before its barrier, so both rows' reads have returned before anyone passes the barrier that precedes the refill.
-// One counted wait per K-tile: at the end of p3's L, vmcnt(4) leaves only SB0(T+2), SA0(T+2) in flight, i.e. all of tile T+1
-// has landed for this wave; the other row's waves wait one barrier later, still before the first read of tile T+1 (row 0 reads
-// two barriers after its own wait).  The activation halves (HBM / Infinity Cache) are issued 4-5 phases before they are read.
+// from SA[its row] and weight rows only from SB[its column pair].  K-tile T lives in buffer T & 1 and is refilled with K-tile
+// T+2 as soon as its last reader is done -- every half-tile is in flight for a whole K-tile (~3000 cycles) before its first use:
+//     L0(T): read A[rows 0-63 of the wave], B (both 32-row parts)
+//     L1(T): read A[rows 64-127]; stage SB0, SB1 of K-tile T+2 (all 8 waves: both rows finished reading SB(T) in their L0,
+//            the later of which ended one barrier ago); ONE counted wait, vmcnt(4) = everything but those four instructions,
+//            i.e. all of K-tile T+1 (issued during K-tile T-1) has landed for this wave
+//     M1(T): stage SA[own row] of K-tile T+2 -- each wave row stages its OWN activation half, whose only readers are its own
+//            four waves, all past the barrier that closed L1 -- then the MFMAs
+// Wave row 1 passes its wait in global interval 4T+3, row 0 first reads K-tile T+1 in interval 4T+4.  (r02 history: a four-phase
+// form, 16 MFMAs per phase, all waves staging every half and two of the four halves issued only 2-3 phases before their use:
+// 1667 us per layer; its 12-read phase and the short prefetch distance both showed as matrix-pipe idle time.)
 template <int BM, int BN>
 struct PPCfg {
     static_assert(BM == 256 && BN == 256, "ping-pong loop is written for the 256 x 256 tile");
@@ -208,7 +212,8 @@ __device__ __forceinline__ void pp_wait_vm4() { asm volatile("s_waitcnt vmcnt(4)
 __device__ __forceinline__ void pp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int BM, int BN>
+// ABL (timing experiments only, results are wrong): bit 0 = no LDS-DMA in the loop, 1 = no fragment reads, 2 = no MFMAs, 3 = no barriers
+template <int BM, int BN, int ABL = 0>
 __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                             const bf16_t* __restrict__ A2, int lda2, const bf16_t* __restrict__ B2, int ldb2,
                                             int M, int N, int K, int K2, int m0, int n0, char* smem, f32x4 (&acc)[4][8], bool perm_b) {
@@ -220,55 +225,78 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
     const int nk = K >> 6;
     const int nk2 = A2 ? (K2 >> 5) : 0;
     const int nt = nk + nk2;
+    const int rl = lane >> 3, cl = lane & 7;
 
-    // per-lane source byte offsets of this wave's two LDS-DMA instructions per half-tile (row clamp + source swizzle)
-    uint32_t offA[2][2], offB[2][2];
+    // per-lane source byte offsets (row clamp + source swizzle) of this wave's LDS-DMA instructions:
+    //   own activation half SA[wm]: 4 instructions, 8 rows each: half-tile rows (j * 4 + wn) * 8 ...
+    //   weight halves SB0, SB1:     2 instructions each:          half-tile rows (j * 8 + wave) * 8 ...
+    uint32_t offA[4], offB[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 4 + wn) * 8 + rl;
+        int ga = m0 + 128 * wm + r;
+        ga = ga < M - 1 ? ga : M - 1;
+        offA[j] = (uint32_t)ga * (uint32_t)lda * 2u + (uint32_t)swz(r, cl) * 16u;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = (j * 8 + wave) * 8 + (lane >> 3);                 // row inside the half-tile
-            const int c = swz(r, lane & 7);
-            int ga = m0 + 128 * h + r;
-            ga = ga < M - 1 ? ga : M - 1;
-            offA[h][j] = (uint32_t)ga * (uint32_t)lda * 2u + (uint32_t)c * 16u;
+            const int r = (j * 8 + wave) * 8 + rl;
             const int rb = 128 * h + r;
             int gb = n0 + (perm_b ? perm32(rb) : rb);
             gb = gb < N - 1 ? gb : N - 1;
-            offB[h][j] = (uint32_t)gb * (uint32_t)ldb * 2u + (uint32_t)c * 16u;
+            offB[h][j] = (uint32_t)gb * (uint32_t)ldb * 2u + (uint32_t)swz(r, cl) * 16u;
         }
-    // stage half-tile `which` (0 SA0, 1 SA1, 2 SB0, 3 SB1) of K-tile t into buffer buf
-    auto stage_half = [&](int t, int buf, int which) {
-        char* dst = smem + buf * C::BUF_BYTES + which * C::HALF_BYTES;
-        const int h = which & 1;
-        if (t < nk) {
-            const char* src = (which < 2 ? (const char*)A : (const char*)B) + (size_t)t * 128;
+    // steady state (a full 64-wide K-tile): no conditions, the K offset is the only run-time term
+    auto stage_a = [&](int t, int buf) {
+        if constexpr (ABL & 1) return;
+        char* dst = smem + buf * C::BUF_BYTES + wm * C::HALF_BYTES;
+        const char* src = (const char*)A + (size_t)t * 128;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t o = which < 2 ? offA[h][j] : offB[h][j];
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + o), (lptr_t)(dst + (j * 8 + wave) * 8 * 128), 16, 0, 0);
-            }
-        } else {                                                            // LoRA half-step: 32 k, only chunks 0..3 are meaningful
-            const int k2 = (t - nk) << 5;
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[j]), (lptr_t)(dst + (j * 4 + wn) * 8 * 128), 16, 0, 0);
+    };
+    auto stage_b = [&](int t, int buf) {
+        if constexpr (ABL & 1) return;
+        const char* src = (const char*)B + (size_t)t * 128;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = (j * 8 + wave) * 8 + (lane >> 3);
-                const int c = swz(r, lane & 7) & 3;
-                const bf16_t* g;
-                if (which < 2) {
-                    int ga = m0 + 128 * h + r;
-                    ga = ga < M - 1 ? ga : M - 1;
-                    g = A2 + (size_t)ga * lda2 + k2 + c * 8;
-                } else {
-                    const int rb = 128 * h + r;
-                    int gb = n0 + (perm_b ? perm32(rb) : rb);
-                    gb = gb < N - 1 ? gb : N - 1;
-                    g = B2 + (size_t)gb * ldb2 + k2 + c * 8;
-                }
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (j * 8 + wave) * 8 * 128), 16, 0, 0);
-            }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + offB[h][j]),
+                                                 (lptr_t)(smem + buf * C::BUF_BYTES + (2 + h) * C::HALF_BYTES + (j * 8 + wave) * 8 * 128), 16, 0, 0);
+    };
+    // LoRA half-step (32 k, only 16-byte chunks 0..3 of a row are meaningful): same rows, addresses computed in place
+    auto stage_a2 = [&](int t, int buf) {
+        char* dst = smem + buf * C::BUF_BYTES + wm * C::HALF_BYTES;
+        const int k2 = (t - nk) << 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 4 + wn) * 8 + rl;
+            int ga = m0 + 128 * wm + r;
+            ga = ga < M - 1 ? ga : M - 1;
+            const bf16_t* g = A2 + (size_t)ga * lda2 + k2 + (swz(r, cl) & 3) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (j * 4 + wn) * 8 * 128), 16, 0, 0);
         }
     };
+    auto stage_b2 = [&](int t, int buf) {
+        const int k2 = (t - nk) << 5;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (j * 8 + wave) * 8 + rl;
+                const int rb = 128 * h + r;
+                int gb = n0 + (perm_b ? perm32(rb) : rb);
+                gb = gb < N - 1 ? gb : N - 1;
+                const bf16_t* g = B2 + (size_t)gb * ldb2 + k2 + (swz(r, cl) & 3) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + buf * C::BUF_BYTES + (2 + h) * C::HALF_BYTES + (j * 8 + wave) * 8 * 128), 16, 0, 0);
+            }
+    };
+    auto stage_a_any = [&](int t, int buf) { if (t < nk) stage_a(t, buf); else stage_a2(t, buf); };
+    auto stage_b_any = [&](int t, int buf) { if (t < nk) stage_b(t, buf); else stage_b2(t, buf); };
+
     // fragment reads: lane-constant part of the address (16-row sub-tiles start at multiples of 16 rows: the swizzle term only
     // depends on the row inside the sub-tile)
     const int frow = lane & 15, fq = lane >> 4;
@@ -278,79 +306,77 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
     const int a_base = wm * C::HALF_BYTES;                                   // SA[wm]
     const int b_base = (2 + (wn >> 1)) * C::HALF_BYTES + (wn & 1) * 64 * 128; // SB[wn >> 1], this wave's 64 weight rows
     bf16x8 af[4][2], bfr[2][2][2];
+    if constexpr (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { af[i][ks] = bf16x8{1, 2, 3, 4, 5, 6, 7, (short)lane}; bfr[i >> 1][i & 1][ks] = af[i][ks]; }
+    }
     // (NKS is a compile-time constant: with a run-time k-half count hipcc turns the fragment arrays into scratch memory)
     auto read_a = [&](int buf, int a, auto nks_c) {
         constexpr int NKS = decltype(nks_c)::value;
+        if constexpr (ABL & 2) return;
         const char* base = smem + buf * C::BUF_BYTES + a_base + a * 64 * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) af[i][ks] = *(const bf16x8*)(base + i * 16 * 128 + foff[ks]);
     };
-    auto read_b0 = [&](int buf, auto nks_c) {
+    auto read_b = [&](int buf, auto nks_c) {
         constexpr int NKS = decltype(nks_c)::value;
+        if constexpr (ABL & 2) return;
         const char* base = smem + buf * C::BUF_BYTES + b_base;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) bfr[0][j][ks] = *(const bf16x8*)(base + j * 16 * 128 + foff[ks]);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) bfr[b][j][ks] = *(const bf16x8*)(base + (b * 32 + j * 16) * 128 + foff[ks]);
     };
-    auto read_b1 = [&](int buf, auto nks_c) {
-        constexpr int NKS = decltype(nks_c)::value;
-        const char* base = smem + buf * C::BUF_BYTES + b_base + 32 * 128;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) bfr[1][j][ks] = *(const bf16x8*)(base + j * 16 * 128 + foff[ks]);
-    };
-    auto quad = [&](auto a_c, auto b_c, auto nks_c) {
-        constexpr int NKS = decltype(nks_c)::value, a = decltype(a_c)::value, b = decltype(b_c)::value;
+    auto half = [&](auto a_c, auto nks_c) {                                   // 32 MFMAs: output rows a*64 .. a*64+63 of the wave
+        constexpr int NKS = decltype(nks_c)::value, a = decltype(a_c)::value;
+        if constexpr (ABL & 4) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[2 * b + j][4 * a + i] = mfma16(bfr[b][j][ks], af[i][ks], acc[2 * b + j][4 * a + i]);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[2 * b + j][4 * a + i] = mfma16(bfr[b][j][ks], af[i][ks], acc[2 * b + j][4 * a + i]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    auto ktile = [&](int T, int cur, auto nks_c) {
-        // ---- phase 0: quadrant (0, 0)
-        read_a(cur, 0, nks_c); read_b0(cur, nks_c);
-        if (T + 1 < nt) stage_half(T + 1, cur ^ 1, 1);
+    auto ktile = [&](int T, int cur, auto nks_c, auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value != 0;                  // T + 2 < nk: one branch-free basic block
+        read_a(cur, 0, nks_c); read_b(cur, nks_c);
         pp_wait_lgkm0(); bar();
-        quad(I0{}, I0{}, nks_c); bar();
-        // ---- phase 1: quadrant (0, 1)
-        read_b1(cur, nks_c);
-        if (T + 1 < nt) stage_half(T + 1, cur ^ 1, 3);
-        pp_wait_lgkm0(); bar();
-        quad(I0{}, I1{}, nks_c); bar();
-        // ---- phase 2: quadrant (1, 1)
+        half(I0{}, nks_c); bar();
         read_a(cur, 1, nks_c);
-        if (T + 2 < nt) stage_half(T + 2, cur, 2);
+        if constexpr (FAST) { stage_b(T + 2, cur); pp_wait_vm4(); }
+        else if (T + 2 < nt) { stage_b_any(T + 2, cur); pp_wait_vm4(); } else { pp_wait_vm0(); }
         pp_wait_lgkm0(); bar();
-        quad(I1{}, I1{}, nks_c); bar();
-        // ---- phase 3: quadrant (1, 0); the one counted wait of the K-tile
-        if (T + 2 < nt) { stage_half(T + 2, cur, 0); pp_wait_vm4(); } else { pp_wait_vm0(); }
-        bar();
-        quad(I1{}, I0{}, nks_c); bar();
+        if constexpr (FAST) stage_a(T + 2, cur); else if (T + 2 < nt) stage_a_any(T + 2, cur);
+        half(I1{}, nks_c); bar();
     };
 
-    // prologue: all of tile 0, the first two halves of tile 1 (the steady-state issue order)
-    stage_half(0, 0, 2); stage_half(0, 0, 0); stage_half(0, 0, 1); stage_half(0, 0, 3);
-    if (nt > 1) { stage_half(1, 1, 2); stage_half(1, 1, 0); pp_wait_vm4(); } else { pp_wait_vm0(); }
+    // prologue: K-tiles 0 and 1 in the steady-state issue order
+    stage_b_any(0, 0); stage_a_any(0, 0);
+    if (nt > 1) { stage_b_any(1, 1); stage_a_any(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } else { pp_wait_vm0(); }
     bar();
     if (wm == 1) bar();                                                      // wave row 1 runs one barrier behind
     int cur = 0;
-    for (int T = 0; T < nk; ++T) { ktile(T, cur, I2{}); cur ^= 1; }
-    for (int T = nk; T < nt; ++T) { ktile(T, cur, I1{}); cur ^= 1; }          // LoRA half-steps (32 k)
+    int T = 0;
+    for (; T + 2 < nk; ++T) { ktile(T, cur, I2{}, I1{}); cur ^= 1; }
+    for (; T < nk; ++T) { ktile(T, cur, I2{}, I0{}); cur ^= 1; }
+    for (; T < nt; ++T) { ktile(T, cur, I1{}, I0{}); cur ^= 1; }             // LoRA half-steps (32 k)
     if (wm == 0) bar();                                                      // re-align the two wave rows
 }
 

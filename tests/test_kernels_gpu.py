@@ -141,6 +141,66 @@ def test_gemm_epilogues(ops):
     assert rel_err(xr[:, 1:], ref) < 2e-5 and float(xr[:, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('tile', [0, 12, 3])
+def test_gemm_large_tile_paths(ops, tile):
+    """The 256 x 256 ping-pong tile (12), the 128 x 128 tile (3) and the
+    default dispatch (0) on the training-size shapes they serve, with every lean epilogue and the LoRA K extension; ragged M."""
+    from prcv2025reid_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(77 + tile)
+    M, K, r, nmod, S = 64 * 197 - 8, 768, 8, 4, 197                     # 12600 rows: the last tile row is ragged
+    Rp = 32
+    x = bf(torch.randn(M, K, device='cuda', generator=g))
+    xf = x.float()
+    _lib.check(_lib.lib().reid_set_knob(b'GEMM_TILE', tile if tile else -1))
+    try:
+        # qkv-like: 16-bit output, LoRA extension with three projection groups
+        N = 2304
+        W = bf(torch.randn(N, K, device='cuda', generator=g) * 0.03); bias = torch.randn(N, device='cuda', generator=g) * 0.1
+        T = bf(torch.randn(M, 3 * Rp, device='cuda', generator=g) * 0.2); B2 = bf(torch.randn(N, Rp, device='cuda', generator=g) * 0.1)
+        out16 = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(x, W, out16, A2=T, B2=B2, K2=Rp, k2_group_n=768, bias=bias)
+        ref = xf @ W.float().t() + bias
+        for gi in range(3):
+            ref[:, gi * 768:(gi + 1) * 768] += T.float()[:, gi * Rp:(gi + 1) * Rp] @ B2.float()[gi * 768:(gi + 1) * 768].t()
+        assert rel_err(out16.float(), ref) < 1e-2
+        out32 = torch.empty(M, N, device='cuda')
+        ops.gemm(x, W, out32, A2=T, B2=B2, K2=Rp, k2_group_n=768, bias=bias)
+        assert rel_err(out32, ref) < 2e-5
+        # out-projection-like: fp32 residual stream, per-row scale (DropPath), LoRA extension
+        N = 768
+        W = bf(torch.randn(N, K, device='cuda', generator=g) * 0.03); bias = torch.randn(N, device='cuda', generator=g) * 0.1
+        B2 = bf(torch.randn(N, Rp, device='cuda', generator=g) * 0.1)
+        R = torch.randn(M, N, device='cuda', generator=g)
+        rs = (torch.rand(64, device='cuda', generator=g) > 0.2).float() / 0.8          # per sample (DropPath)
+        out = torch.empty(M, N, device='cuda')
+        ops.gemm(x, W, out, A2=T[:, :Rp], B2=B2, K2=Rp, bias=bias, R=R, row_scale=rs, rows_per_img=S)
+        row_rs = rs[torch.arange(M, device='cuda') // S]
+        ref = (xf @ W.float().t() + bias + T.float()[:, :Rp] @ B2.float().t()) * row_rs[:, None] + R
+        assert rel_err(out, ref) < 2e-5
+        # fc1-like: GELU with the pre-activation kept; then its backward form
+        N = 3072
+        W = bf(torch.randn(N, K, device='cuda', generator=g) * 0.03); bias = torch.randn(N, device='cuda', generator=g) * 0.1
+        h = torch.empty(M, N, device='cuda', dtype=T16()); u = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(x, W, h, bias=bias, act='gelu', C2=u)
+        base = xf @ W.float().t() + bias
+        assert rel_err(u.float(), base) < 1e-2
+        assert rel_err(h.float(), torch.nn.functional.gelu(base)) < 1e-2
+        uf = u.float().requires_grad_(True)
+        torch.nn.functional.gelu(uf).sum().backward()
+        y = bf(torch.randn(M, K, device='cuda', generator=g))
+        W2 = bf(torch.randn(N, K, device='cuda', generator=g) * 0.03)   # dU = (dY W2^T) * gelu'(u): [M, 768] x [3072, 768]^T
+        du = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(y, W2, du, act='dgelu', aux=u)
+        assert rel_err(du.float(), (y.float() @ W2.float().t()) * uf.grad) < 1e-2
+        # fc2-like: K = 3072 into the residual stream
+        A = h
+        W = bf(torch.randn(768, 3072, device='cuda', generator=g) * 0.02)
+        ops.gemm(A, W, out, R=R)
+        assert rel_err(out, A.float() @ W.float().t() + R) < 2e-5
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'GEMM_TILE', -1))
+
+
 @pytest.mark.parametrize('M,P,Q', [(1000, 768, 32), (4099, 32, 768), (777, 3072, 64), (5000, 96, 768), (2048, 256, 384),
                                    (63, 768, 32)])
 def test_gemm_tn(ops, M, P, Q):

@@ -17,6 +17,17 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+def knob(name, v):
+    _lib.check(_lib.lib().reid_set_knob(name.encode(), v))
 for dbg in (3, 2, 1, 0):
-    os.environ['REID_ATTN_DBG'] = str(dbg)
-    print('dbg', dbg, round(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)), 1), 'us')
+    knob('ATTN_DBG', dbg if dbg else -1)
+    print('dbg', dbg, round(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)), 1), 'us', flush=True)
+ref = o.clone()
+for split in (0,):
+    for stag in (0, 1, 2, 3, 102, 103):
+        knob('ATTN_SPLIT', split or -1); knob('ATTN_STAGGER', stag or -1)
+        res = []
+        for _ in range(3):
+            res.append(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)))
+        print('split', split, 'stagger', stag, round(min(res), 1), 'us  equal', bool(torch.equal(o, ref)), flush=True)
+knob('ATTN_SPLIT', -1); knob('ATTN_STAGGER', -1)
