@@ -467,6 +467,9 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
         // every score against its row threshold 0.7 ms, candidate appends 0.6 ms; 128x128 / 128x256 / 256x128 tiles all end
         // at 4.0-4.1 ms per top-10 call.  Tried and dropped: a persistent variant with a 3-stage ring across tiles (4.02 ms: the
         // per-tile latency it removes is not the bottleneck), the 256x256 tile (fastest K loop, but its epilogue spills).
+        // r02: the MER GEMM's wave-row ping-pong K loop (gemm_core.h mainloop_pp) under this epilogue, 256x256: 4.68 ms against 4.10 ms
+        // for the default on the same box (profiles/r02_retrieval_tiles_pingpong.log, patch next to it): the loop leaves the compare
+        // epilogue no registers (176-228 B/lane of scratch in it), and the epilogue, not the K loop, is what this pass waits on.
         const int tile = reid_knob(KNOB_TOPK_TILE) >= 0 ? reid_knob(KNOB_TOPK_TILE) : 2;
         int rc;
         if (tile == 1) rc = launch_filter<256, 128, 4, 2>(p, s);
