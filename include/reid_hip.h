@@ -41,7 +41,10 @@ typedef enum {
     REID_ACT_RELU = 3,        /* models/model.py:42                                   */
     REID_ACT_DGELU_ERF = 4,   /* out = acc * gelu'(aux)        (backward of 1)        */
     REID_ACT_DQUICK_GELU = 5, /* out = acc * quick_gelu'(aux)  (backward of 2)        */
-    REID_ACT_DRELU = 6        /* out = acc * (aux > 0)                                */
+    REID_ACT_DRELU = 6,       /* out = acc * (aux > 0)                                */
+    REID_ACT_MUL_AUX = 7,     /* out = acc * aux               (backward of 8: aux = the saved derivative)          */
+    REID_ACT_GELU_ERF_DSAVE = 8 /* out = gelu(acc), C2 = gelu'(acc) instead of the pre-activation: the backward
+                                 * product is then one multiply per element (7) instead of erfc + exp            */
 } reid_act;
 
 const char* reid_last_error(void);

@@ -29,7 +29,7 @@ def t16() -> torch.dtype:
 
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU = range(7)
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_MUL_AUX, ACT_GELU_DSAVE = range(9)
 
 EXPORTS = [
     'reid_last_error', 'reid_version', 'reid_flavor', 'reid_check_device', 'reid_set_knob', 'reid_mer_gemm', 'reid_gemm_tn',

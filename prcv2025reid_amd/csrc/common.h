@@ -16,7 +16,7 @@ void reid_set_error(const char* fmt, ...);
 // Experiment knobs (tile choice, early-exit builds, pipeline parameters): ONE cached table per process, filled from the
 // environment (REID_<NAME>) on first use and changed afterwards only through reid_set_knob() -- no getenv() on the launch path.
 enum reid_knob_id {
-    KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI,
+    KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI, KNOB_GEMM_STAGGER,
     KNOB_ATTN_DBG, KNOB_ATTN_STAGGER, KNOB_ATTN_SPLIT, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_SDM_IMPL, KNOB_COUNT
 };
 int reid_knob(int id);
@@ -101,6 +101,12 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     float c, e;
     gauss_cdf_pdf(x, c, e);
     return x * c;
+}
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {      // one erfc / exp for value and derivative
+    float c, e;
+    gauss_cdf_pdf(x, c, e);
+    g = x * c;
+    dg = fmaf(x * 0.39894228040143268f, e, c);
 }
 __device__ __forceinline__ float dgelu_erf_f(float x) {
     float c, e;

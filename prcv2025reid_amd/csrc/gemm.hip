@@ -33,6 +33,7 @@ struct GemmParams {
     float alpha;
     int tiles_m, tiles_n;
     int group_m;  // row tiles per L2 group of the tile order (gemm_core.h tile_coords)
+    int stagger;  // ping-pong kernel: spread (in 0.25 us units) of the start times of the first round of workgroups
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
     int epi;      // EPI_*: which epilogue the kernel instance was built with (host side choice)
@@ -43,7 +44,10 @@ struct GemmParams {
 // 3-4 TB/s where plain 16-byte stores of the same shape reach 7 TB/s (r02: tools/store_patterns.hip, REID_GEMM_DBG=4).  The four
 // kinds below cover the seven ViT GEMM variants of a training step with straight-line code (32-bit offsets, one predicate per
 // row, no option tests); everything else (patch embed row remap, routing masks, alpha, quick-GELU, ...) stays on GENERIC.
-enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4 };
+// GELU2D / MULAUX (r02): the training path saves gelu'(u) in the forward epilogue -- it shares the erfc and exp of the value -- so
+// the backward epilogue is one multiply per element instead of ~23 VALU operations (epilogues of this family are VALU-bound at
+// two waves per SIMD: ~12 us per 256 x 256 tile, tools/exp_epilogue_scale.py).
+enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4, EPI_GELU2D = 5, EPI_MULAUX = 6 };
 
 using namespace gemmcore;
 
@@ -130,7 +134,7 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
     const int frow = lane & 15, fq = lane >> 4;
     const int mlast = p.M - 1;
     const bool has_r = p.R != nullptr;
-    const bool has_aux = p.act >= REID_ACT_DGELU_ERF;
+    const bool has_aux = p.act >= REID_ACT_DGELU_ERF && p.act <= REID_ACT_MUL_AUX;
     Piece<CW> rv[RD];
     typedef typename std::conditional<CW == 8, bf16x8, bf16x4>::type aux_t;   // saved pre-activations stay packed
     aux_t av[RD];
@@ -168,9 +172,17 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
 #pragma unroll
             for (int e = 0; e < CW; ++e) v[e] += rv[slot].v[e];
         }
-        if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, v);
-        if (p.act != REID_ACT_NONE) {
-            if (p.act == REID_ACT_GELU_ERF) {               // (uniform branches: only the selected activation is evaluated)
+        if (p.act == REID_ACT_GELU_ERF_DSAVE) {             // value to C, DERIVATIVE (not the pre-activation) to C2
+            float dv[CW];
+#pragma unroll
+            for (int e = 0; e < CW; ++e) gelu_both_f(v[e], v[e], dv[e]);
+            if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, dv);
+        } else if (p.C2 && ok) store_piece<CW>(p.C2, p.c2_dtype, crow * p.ldc2 + n, v);
+        if (p.act != REID_ACT_NONE && p.act != REID_ACT_GELU_ERF_DSAVE) {
+            if (p.act == REID_ACT_MUL_AUX) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] *= bf16_to_f32((bf16_t)av[slot][e]);
+            } else if (p.act == REID_ACT_GELU_ERF) {        // (uniform branches: only the selected activation is evaluated)
 #pragma unroll
                 for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
             } else if (p.act == REID_ACT_QUICK_GELU) {
@@ -243,12 +255,12 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
             const int mc = ok ? m : p.M - 1;
             const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 2u;
             bf16x8 av[NP];
-            if constexpr (EPI == EPI_DGELU) {
+            if constexpr (EPI == EPI_DGELU || EPI == EPI_MULAUX) {
                 const uint32_t ao = ((uint32_t)mc * (uint32_t)p.ldaux + col) * 2u;
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc) av[pc] = *(const bf16x8*)((const char*)p.aux + ao + 64u * pc);
             }
-            const uint32_t c2o = EPI == EPI_GELU2 ? ((uint32_t)mc * (uint32_t)p.ldc2 + col) * 2u : 0u;
+            const uint32_t c2o = (EPI == EPI_GELU2 || EPI == EPI_GELU2D) ? ((uint32_t)mc * (uint32_t)p.ldc2 + col) * 2u : 0u;
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 float v[8];
@@ -258,9 +270,17 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
                     if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if constexpr (EPI == EPI_GELU2D) {
+                    float dv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
+                    if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]), pack_bf16x2(dv[4], dv[5]), pack_bf16x2(dv[6], dv[7])};
                 } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[pc][e]));
+                } else if constexpr (EPI == EPI_MULAUX) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= bf16_to_f32((bf16_t)av[pc][e]);
                 }
                 if (ok) *(uint4*)(C + co + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             }
@@ -281,6 +301,8 @@ static int pick_epilogue(const GemmParams& p, int BN) {
     if (p.act == REID_ACT_NONE && !p.C2 && !p.aux) return EPI_PLAIN16;
     if (p.act == REID_ACT_GELU_ERF && p.C2 && p.c2_dtype != REID_F32 && !p.aux) return EPI_GELU2;
     if (p.act == REID_ACT_DGELU_ERF && p.aux && !p.C2) return EPI_DGELU;
+    if (p.act == REID_ACT_GELU_ERF_DSAVE && p.C2 && p.c2_dtype != REID_F32 && !p.aux) return EPI_GELU2D;
+    if (p.act == REID_ACT_MUL_AUX && p.aux && !p.C2) return EPI_MULAUX;
     return EPI_GENERIC;
 }
 
@@ -337,6 +359,12 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        // first round only: CU c of every XCD starts c/32 of the spread late, so the epilogues of the chip's 256 tiles in flight
+        // do not all hit HBM in the same few microseconds (see launch_pp)
+        const int n = ((blockIdx.x >> 3) & 31) * p.stagger >> 5;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);            // 8 x 64 cycles ~ 0.25 us
+    }
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
@@ -384,11 +412,14 @@ int launch_pp(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 256);
+    p.stagger = reid_knob(KNOB_GEMM_STAGGER) > 0 ? reid_knob(KNOB_GEMM_STAGGER) : 0;
     switch (p.epi) {
         case EPI_PLAIN16: return launch_pp_e<EPI_PLAIN16>(p, s);
         case EPI_RES32: return launch_pp_e<EPI_RES32>(p, s);
         case EPI_GELU2: return launch_pp_e<EPI_GELU2>(p, s);
         case EPI_DGELU: return launch_pp_e<EPI_DGELU>(p, s);
+        case EPI_GELU2D: return launch_pp_e<EPI_GELU2D>(p, s);
+        case EPI_MULAUX: return launch_pp_e<EPI_MULAUX>(p, s);
         default: return launch_pp_e<EPI_GENERIC>(p, s);
     }
 }
@@ -415,6 +446,8 @@ int launch_main(GemmParams& p, hipStream_t s) {
         case EPI_RES32: return launch_e<128, 128, 2, 2, EPI_RES32>(p, s);
         case EPI_GELU2: return launch_e<128, 128, 2, 2, EPI_GELU2>(p, s);
         case EPI_DGELU: return launch_e<128, 128, 2, 2, EPI_DGELU>(p, s);
+        case EPI_GELU2D: return launch_e<128, 128, 2, 2, EPI_GELU2D>(p, s);
+        case EPI_MULAUX: return launch_e<128, 128, 2, 2, EPI_MULAUX>(p, s);
         default: return launch_e<128, 128, 2, 2, EPI_GENERIC>(p, s);
     }
 }
@@ -457,8 +490,9 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         REID_CHECK_ARG(a->lda2 >= groups * a->K2, "reid_mer_gemm: lda2=%d < groups*K2=%d", a->lda2, groups * a->K2);
         REID_CHECK_ARG(a->k2_group_n == 0 || a->k2_group_n % 128 == 0, "reid_mer_gemm: k2_group_n must be a multiple of 128");
     }
-    REID_CHECK_ARG(a->act >= 0 && a->act <= REID_ACT_DRELU, "reid_mer_gemm: act=%d", a->act);
-    REID_CHECK_ARG(a->act < REID_ACT_DGELU_ERF || (a->aux && a->ldaux >= a->N), "reid_mer_gemm: D* activation needs aux");
+    REID_CHECK_ARG(a->act >= 0 && a->act <= REID_ACT_GELU_ERF_DSAVE, "reid_mer_gemm: act=%d", a->act);
+    REID_CHECK_ARG(a->act < REID_ACT_DGELU_ERF || a->act > REID_ACT_MUL_AUX || (a->aux && a->ldaux >= a->N), "reid_mer_gemm: D* / MUL_AUX activation needs aux");
+    REID_CHECK_ARG(a->act != REID_ACT_GELU_ERF_DSAVE || a->C2, "reid_mer_gemm: GELU_ERF_DSAVE needs C2");
     REID_CHECK_ARG(!a->R || a->ldr >= a->N, "reid_mer_gemm: ldr");
     REID_CHECK_ARG(!a->C2 || a->ldc2 >= a->N, "reid_mer_gemm: ldc2");
     REID_CHECK_ARG(a->mask_r == 0 || (a->img_mod && a->rows_per_img > 0 && a->mask_period > 0),
@@ -466,6 +500,7 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     REID_CHECK_ARG(a->c_group == 0 || a->c_group_stride >= a->c_group, "reid_mer_gemm: c_group_stride");
     REID_CHECK_ARG(!a->row_scale || a->rows_per_img > 0, "reid_mer_gemm: row_scale needs rows_per_img");
     GemmParams p;
+    p.stagger = 0;
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.A2 = (const bf16_t*)a->A2; p.B2 = (const bf16_t*)a->B2;
     p.bias = a->bias; p.R = a->R; p.aux = (const bf16_t*)a->aux; p.C = a->C; p.C2 = a->C2; p.img_mod = a->img_mod; p.row_scale = a->row_scale;
     p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->A2 ? a->K2 : 0;

@@ -298,10 +298,10 @@ class Engine:
             ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
             T1 = new('T1', (Mr, Rp), b16)
             ops.gemm(h2, pk(l, 'fc1', 'A'), T1, **mkr)
-            u = new('u', (Mr, ff), b16) if save else None
+            u = new('u', (Mr, ff), b16) if save else None      # holds gelu'(pre-activation): the backward epilogue is one multiply
             g = new('g', (Mr, ff), b16)
             ops.gemm(h2, W[('v', l, 'fc1')], g, A2=T1, B2=pk(l, 'fc1', 'B'), K2=Rp,
-                     bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu', C2=u)
+                     bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu_dsave' if save else 'gelu', C2=u)
             T2 = new('T2', (Mr, Rp), b16)
             ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mkr)
             xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
@@ -432,7 +432,7 @@ class Engine:
             # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
             ops.gemm(gyb, pk(l, 'fc2', 'BT'), U2r, **mkr)
             fork((gyb, s['T2'], gB(l, 'fc2')), (U2r, s['g'], gA(l, 'fc2')))
-            ops.gemm(gyb, W[('v', l, 'fc2T')], dur, A2=U2r, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='dgelu', aux=s['u'])
+            ops.gemm(gyb, W[('v', l, 'fc2T')], dur, A2=U2r, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='mul_aux', aux=s['u'])
             if want_dense:
                 dense[lp + 'mlp.fc2.shared_linear.weight'] = wgrad(gyb, s['g'])
                 dense[lp + 'mlp.fc2.shared_linear.bias'] = colsum(gyb)

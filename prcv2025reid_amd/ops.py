@@ -12,7 +12,8 @@ from . import _lib as L
 from ._lib import BF16, F32, GemmArgs, check, lib, ptr, stream_ptr
 
 ACT = {'none': L.ACT_NONE, 'gelu': L.ACT_GELU, 'quick_gelu': L.ACT_QUICK_GELU, 'relu': L.ACT_RELU,
-       'dgelu': L.ACT_DGELU, 'dquick_gelu': L.ACT_DQUICK_GELU, 'drelu': L.ACT_DRELU}
+       'dgelu': L.ACT_DGELU, 'dquick_gelu': L.ACT_DQUICK_GELU, 'drelu': L.ACT_DRELU,
+       'mul_aux': L.ACT_MUL_AUX, 'gelu_dsave': L.ACT_GELU_DSAVE}
 
 
 # optional per-launch timing of the dominant kernel (bench.py roofline): list of (flops, bytes, start_event, end_event)

@@ -115,6 +115,15 @@ def test_gemm_epilogues(ops):
     ops.gemm(A, B, out, bias=bias, act='gelu', C2=pre)
     assert rel_err(out, torch.nn.functional.gelu(base)) < 2e-5
     assert rel_err(pre.float(), base) < 1e-2
+    # value + saved derivative (the training path's fc1): C2 = gelu'(acc); its backward partner multiplies by the saved factor
+    dsv = torch.empty(M, N, device='cuda', dtype=T16())
+    ops.gemm(A, B, out, bias=bias, act='gelu_dsave', C2=dsv)
+    bb = base.clone().requires_grad_(True)
+    torch.nn.functional.gelu(bb).sum().backward()
+    assert rel_err(out, torch.nn.functional.gelu(base)) < 2e-5
+    assert rel_err(dsv.float(), bb.grad) < 1e-2
+    ops.gemm(A, B, out, act='mul_aux', aux=dsv)
+    assert rel_err(out, (A.float() @ B.float().t()) * dsv.float()) < 2e-5
     ops.gemm(A, B, out, bias=bias, act='quick_gelu')
     assert rel_err(out, base * torch.sigmoid(1.702 * base)) < 2e-5
     ops.gemm(A, B, out, bias=bias, act='relu')
@@ -192,6 +201,15 @@ def test_gemm_large_tile_paths(ops, tile):
         du = torch.empty(M, N, device='cuda', dtype=T16())
         ops.gemm(y, W2, du, act='dgelu', aux=u)
         assert rel_err(du.float(), (y.float() @ W2.float().t()) * uf.grad) < 1e-2
+        # the pair the training path uses: derivative saved by the forward epilogue, one multiply in the backward one
+        dv = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(x, W, h, bias=bias, act='gelu_dsave', C2=dv)
+        bb = base.clone().requires_grad_(True)
+        torch.nn.functional.gelu(bb).sum().backward()
+        assert rel_err(h.float(), torch.nn.functional.gelu(base)) < 1e-2
+        assert rel_err(dv.float(), bb.grad) < 1e-2
+        ops.gemm(y, W2, du, act='mul_aux', aux=dv)
+        assert rel_err(du.float(), (y.float() @ W2.float().t()) * dv.float()) < 1e-2
         # fc2-like: K = 3072 into the residual stream
         A = h
         W = bf(torch.randn(768, 3072, device='cuda', generator=g) * 0.02)

@@ -30,6 +30,8 @@ cases = [
  ('fc1  bf16+gelu+C2     ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, bias=b1, act='gelu', C2=u)),
  ('fc2  f32+bias+R K=3072', 2.0*M*d*(ff+Rp), lambda: ops.gemm(gact, W2, xo, A2=T[:, :Rp], B2=Bo, K2=Rp, bias=bo, R=x)),
  ('fc2b bf16+dgelu(aux)  ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, act='dgelu', aux=u)),
+ ('fc1d bf16+gelu+dsave  ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, bias=b1, act='gelu_dsave', C2=u)),
+ ('fc2m bf16*aux         ', 2.0*M*ff*(d+Rp), lambda: ops.gemm(h, W1, g2, A2=T[:, :Rp], B2=B1, K2=Rp, act='mul_aux', aux=u)),
  ('fc1b bf16 K=3072      ', 2.0*M*d*(ff+Rp), lambda: ops.gemm(gact, W2, dh, A2=T[:, :Rp], B2=Bo, K2=Rp)),
  ('qkvb bf16 K=2304+96   ', 2.0*M*d*(3*d+3*Rp), lambda: ops.gemm(qkv, rnd(d, 3*d, scale=0.03), dh, A2=T, B2=rnd(d, 3*Rp, scale=0.1), K2=3*Rp)),
 ]

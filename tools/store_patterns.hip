@@ -51,5 +51,21 @@ int main() {
             printf("waves/CU %d pattern %d: %.1f us  %.2f TB/s  %.1f B/clk/CU at 2.1 GHz\n", waves, pat, best * 1e3, bytes / (best * 1e-3) / 1e12,
                    bytes / 256 / (best * 1e-3) / 2.1e9);
         }
+    // per-CU ceiling: the same stores from FEWER workgroups (the rest of the chip quiet), pattern 0, 8 waves.  In a GEMM only the
+    // workgroups that are in their epilogue store; if one CU alone cannot go faster than its share of 7 TB/s, the epilogue of a
+    // one-workgroup-per-CU kernel costs tile bytes / that rate whatever the others do.
+    for (int n : {8, 32, 64, 128, 256}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(store_kernel<0>, dim3(n), dim3(512), 0, 0, d, ld, rows_per_wg, 8);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        const double bytes = (double)n * rows_per_wg * 256 * 4 * 8;
+        printf("%3d workgroups (1 per CU), 8 waves, pattern 0: %.1f us  %.2f TB/s  %.1f B/clk per active CU at 2.1 GHz\n", n, best * 1e3,
+               bytes / (best * 1e-3) / 1e12, bytes / n / (best * 1e-3) / 2.1e9);
+    }
     return 0;
 }
