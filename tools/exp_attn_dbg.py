@@ -23,11 +23,17 @@ for dbg in (3, 2, 1, 0):
     knob('ATTN_DBG', dbg if dbg else -1)
     print('dbg', dbg, round(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)), 1), 'us', flush=True)
 ref = o.clone()
-for split in (0,):
-    for stag in (0, 1, 2, 3, 102, 103):
-        knob('ATTN_SPLIT', split or -1); knob('ATTN_STAGGER', stag or -1)
-        res = []
-        for _ in range(3):
-            res.append(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)))
-        print('split', split, 'stagger', stag, round(min(res), 1), 'us  equal', bool(torch.equal(o, ref)), flush=True)
-knob('ATTN_SPLIT', -1); knob('ATTN_STAGGER', -1)
+for persist in (0, 1, 2, 3, 4):
+    knob('ATTN_PERSIST', persist)
+    res = [timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)) for _ in range(3)]
+    print(('persistent x%d' % persist) if persist else 'one workgroup per item', round(min(res), 1), 'us  equal', bool(torch.equal(o, ref)), flush=True)
+knob('ATTN_PERSIST', -1)
+# backward
+do = (torch.randn(M, d, device='cuda', generator=g)).to(T16); dqkv = torch.empty(M, 3 * d, device='cuda', dtype=T16)
+delta = torch.empty(n_img, heads, S, device='cuda')
+ops.attn_bwd(qkv, o, do, lse, dqkv, delta, n_img, S, heads); refd = dqkv.clone()
+for persist in (0, 1, 2, 3):
+    knob('ATTN_PERSIST', persist)
+    res = [timeit(lambda: ops.attn_bwd(qkv, o, do, lse, dqkv, delta, n_img, S, heads)) for _ in range(3)]
+    print('bwd (delta + dkv + dq):', ('persistent x%d' % persist) if persist else 'one workgroup per item', round(min(res), 1), 'us  equal', bool(torch.equal(dqkv, refd)), flush=True)
+knob('ATTN_PERSIST', -1)
