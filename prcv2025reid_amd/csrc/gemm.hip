@@ -37,6 +37,7 @@ struct GemmParams {
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
     int epi;      // EPI_*: which epilogue the kernel instance was built with (host side choice)
+    unsigned long long* trace;   // REID_GEMM_TRACE builds: 8 words per workgroup (timestamps at start / loop end / epilogue issued / acknowledged, HW ids)
 };
 
 // Epilogue kinds.  The GENERIC epilogue evaluates every option of reid_mer_gemm at run time (~100-600 instructions per 16-byte
@@ -221,45 +222,75 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
 // Lean epilogues (host side guarantees: N a multiple of the tile, every stride a multiple of 8 elements, every operand below
 // 4 GiB, alpha == 1, no mask / row remap / periodic residual).  Layout as in store_tile_m: the 16-bit kinds use the perm32
 // weight-row staging (a lane owns 8 consecutive columns per pair of MFMA sub-tiles), EPI_RES32 the natural one (4 columns).
+// aux_lds != nullptr (256 x 256 ping-pong kernel, MULAUX): the tile of the aux operand sits in LDS as [256 rows][512 B] with the
+// 16-byte chunks of row r stored at position chunk ^ (r & 15) (stage_aux_tile below); lrow0 / lchunk0 = this wave's first row /
+// first chunk in that image.
 template <int TM, int TN, int EPI>
-__device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+__device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane,
+                                                const char* aux_lds = nullptr, int lrow0 = 0, int lchunk0 = 0) {
     const int frow = lane & 15, fq = lane >> 4;
+    // Operand loads (residual, saved derivative) are ALL issued before the first use, half a tile at a time: one exposed memory
+    // round trip per half instead of one per 16-row group (the per-group form cost the multiply-by-aux epilogue 9 of its 15 us per
+    // tile -- eight dependent load -> use steps per wave -- although it moves the same bytes as the plain 16-bit epilogue's stores).
     if constexpr (EPI == EPI_RES32) {
         const uint32_t col = (uint32_t)(n_base + 4 * fq);
         char* C = (char*)p.C; const char* R = (const char*)p.R;
+        constexpr int HG = TM / 2;                                                   // 16-row groups per half
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m_base + 16 * i + frow;
-            const bool ok = m < p.M;
-            const int mc = ok ? m : p.M - 1;
-            const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 4u, ro = ((uint32_t)mc * (uint32_t)p.ldr + col) * 4u;
-            f32x4 r[TN];
+        for (int half = 0; half < 2; ++half) {
+            f32x4 r[HG][TN];
+            float rs[HG];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) r[j] = *(const f32x4*)(R + ro + 64u * j);
-            float rs = 1.f;
-            if (p.row_scale) rs = p.row_scale[mc / p.rows_per_img];               // DropPath: the branch output of this sample
+            for (int ii = 0; ii < HG; ++ii) {
+                const int m = m_base + 16 * (half * HG + ii) + frow;
+                const int mc = m < p.M ? m : p.M - 1;
+                const uint32_t ro = ((uint32_t)mc * (uint32_t)p.ldr + col) * 4u;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const f32x4 v = acc[j][i] * rs + r[j];
-                if (ok) *(f32x4*)(C + co + 64u * j) = v;
+                for (int j = 0; j < TN; ++j) r[ii][j] = *(const f32x4*)(R + ro + 64u * j);
+                rs[ii] = p.row_scale ? p.row_scale[mc / p.rows_per_img] : 1.f;       // DropPath: the branch output of this sample
+            }
+#pragma unroll
+            for (int ii = 0; ii < HG; ++ii) {
+                const int i = half * HG + ii;
+                const int m = m_base + 16 * i + frow;
+                const bool ok = m < p.M;
+                const uint32_t co = ((uint32_t)(ok ? m : p.M - 1) * (uint32_t)p.ldc + col) * 4u;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = acc[j][i] * rs[ii] + r[ii][j];
+                    if (ok) *(f32x4*)(C + co + 64u * j) = v;
+                }
             }
         }
     } else {
         constexpr int NP = TN / 2;                                                   // 8-column pieces per 16-row group
+        constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_MULAUX;
         const uint32_t col = (uint32_t)(n_base + 8 * fq);
         char* C = (char*)p.C;
+        bf16x8 av[HAS_AUX ? TM : 1][NP];
+        if (HAS_AUX && aux_lds) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lr = lrow0 + 16 * i + frow;
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) av[i][pc] = *(const bf16x8*)(aux_lds + lr * 512 + (((lchunk0 + fq + 4 * pc) ^ (lr & 15)) << 4));
+            }
+        } else if constexpr (HAS_AUX) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m_base + 16 * i + frow;
+                const int mc = m < p.M ? m : p.M - 1;
+                const uint32_t ao = ((uint32_t)mc * (uint32_t)p.ldaux + col) * 2u;
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) av[i][pc] = *(const bf16x8*)((const char*)p.aux + ao + 64u * pc);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m_base + 16 * i + frow;
             const bool ok = m < p.M;
             const int mc = ok ? m : p.M - 1;
             const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 2u;
-            bf16x8 av[NP];
-            if constexpr (EPI == EPI_DGELU || EPI == EPI_MULAUX) {
-                const uint32_t ao = ((uint32_t)mc * (uint32_t)p.ldaux + col) * 2u;
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc) av[pc] = *(const bf16x8*)((const char*)p.aux + ao + 64u * pc);
-            }
             const uint32_t c2o = (EPI == EPI_GELU2 || EPI == EPI_GELU2D) ? ((uint32_t)mc * (uint32_t)p.ldc2 + col) * 2u : 0u;
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
@@ -277,10 +308,10 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
                     if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]), pack_bf16x2(dv[4], dv[5]), pack_bf16x2(dv[6], dv[7])};
                 } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[pc][e]));
+                    for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[i][pc][e]));
                 } else if constexpr (EPI == EPI_MULAUX) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= bf16_to_f32((bf16_t)av[pc][e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= bf16_to_f32((bf16_t)av[i][pc][e]);
                 }
                 if (ok) *(uint4*)(C + co + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             }
@@ -359,6 +390,13 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+#ifdef REID_GEMM_TRACE
+#define GEMM_TRACE(slot) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#else
+#define GEMM_TRACE(slot) do { } while (0)
+#endif
+    GEMM_TRACE(0);
     if (p.stagger > 0 && blockIdx.x < 256) {
         // first round only: CU c of every XCD starts c/32 of the spread late, so the epilogues of the chip's 256 tiles in flight
         // do not all hit HBM in the same few microseconds (see launch_pp)
@@ -391,10 +429,44 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
 #endif
     if (p.dbg != 4)
         mainloop_pp<256, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
+    GEMM_TRACE(1);
     if (p.dbg == 1) return;
+    if constexpr (EPI == EPI_MULAUX) {
+        // The saved-derivative tile (256 rows x 512 B) comes in through LDS, which the K loop has just left: 128 LDS-DMA instructions
+        // of two 512-byte row segments each, instead of 128 register loads of sixteen 64-byte row segments -- the register-direct form
+        // kept a workgroup 8.5 us in this epilogue (per-workgroup trace, tools/exp_gemm_trace.py), most of it waiting for those reads.
+        __syncthreads();                                     // every wave has left the K loop's last fragment reads
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rp = q * 8 + wave;                     // row pair
+            const int row = 2 * rp + (lane >> 5);
+            const int c = lane & 31;                         // destination chunk position; it holds source chunk c ^ (row & 15)
+            const int gm = m0 + row < p.M ? m0 + row : p.M - 1;
+            const char* src = (const char*)p.aux + ((size_t)gm * p.ldaux + n0) * 2 + ((c ^ (row & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + rp * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        store_tile_fast<8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem, wm * 128, wn * 8);
+        GEMM_TRACE(2);
+#ifdef REID_GEMM_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_TRACE(3);
+#endif
+        return;
+    }
     if constexpr (EPI == EPI_GENERIC) store_tile<8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
     else store_tile_fast<8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    GEMM_TRACE(2);
+#ifdef REID_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_TRACE(3);
+#endif
 }
+#ifdef REID_GEMM_TRACE
+static unsigned long long* g_gemm_trace = nullptr;
+extern "C" void reid_debug_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; }
+#endif
 
 template <int EPI>
 int launch_pp_e(GemmParams& p, hipStream_t s) {
@@ -413,6 +485,9 @@ int launch_pp(GemmParams& p, hipStream_t s) {
     p.tiles_n = (p.N + 255) / 256;
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 256);
     p.stagger = reid_knob(KNOB_GEMM_STAGGER) > 0 ? reid_knob(KNOB_GEMM_STAGGER) : 0;
+#ifdef REID_GEMM_TRACE
+    p.trace = g_gemm_trace;
+#endif
     switch (p.epi) {
         case EPI_PLAIN16: return launch_pp_e<EPI_PLAIN16>(p, s);
         case EPI_RES32: return launch_pp_e<EPI_RES32>(p, s);
@@ -501,6 +576,7 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     REID_CHECK_ARG(!a->row_scale || a->rows_per_img > 0, "reid_mer_gemm: row_scale needs rows_per_img");
     GemmParams p;
     p.stagger = 0;
+    p.trace = nullptr;
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.A2 = (const bf16_t*)a->A2; p.B2 = (const bf16_t*)a->B2;
     p.bias = a->bias; p.R = a->R; p.aux = (const bf16_t*)a->aux; p.C = a->C; p.C2 = a->C2; p.img_mod = a->img_mod; p.row_scale = a->row_scale;
     p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->A2 ? a->K2 : 0;
