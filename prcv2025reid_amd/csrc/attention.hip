@@ -10,6 +10,14 @@
 // ds_read_b64_tr_b16.  The backward pass is two kernels of the same shape (dK/dV with keys on the
 // lane, dQ with queries on the lane), each needing only products that sum over the accumulator's
 // row index; P is recomputed from the saved log-sum-exp.
+//
+// r02 experiments, measured and not kept (profiles/r02_attn_*.log, r02_attn_persistent_experiment.patch): starting the second
+// workgroup of every CU late, waiting for K only before the first sweep (V lands under it), and PERSISTENT workgroups walking the
+// (sequence, head) items with a grid stride.  The last is 3-5 % faster alone (fwd 105 vs 110 us) but the item loop costs registers (dQ
+// kernel 120 -> 136 VGPRs = one workgroup per CU instead of two: 113 -> 152 us) and, inside the training step, workgroups that start late
+// behind the side-stream reductions still own a fixed share of the items.  Per-workgroup timestamps of the forward kernel: K/V/Q
+// landing 3.9 us, first sweep 3.3, second sweep 3.6, stores 1.2; per item and CU the matrix pipe needs 2.2 us, the exponentials ~3 us,
+// HBM 4 us -- they add up rather than overlap with two 7-wave workgroups per CU.
 #include "common.h"
 #include <stdlib.h>
 
@@ -120,7 +128,6 @@ struct AttnParams {
     int n_seq, S, heads, causal;
     int q_tiles;  // > 0: only the first q_tiles 32-row QUERY tiles of every sequence are computed (all keys still take part)
     int dbg;     // timing experiments (REID_ATTN_DBG): 1 = no output stores, 2 = also no softmax / P.V, 3 = staging only
-    unsigned long long* trace;   // REID_ATTN_TRACE builds only: 8 words per workgroup (timestamps at the phase boundaries, HW_ID)
 };
 
 // A 32x32 MFMA result tile holds, for the row on lanes l and l+32, the two 4-element halves of every 8-element column
@@ -139,13 +146,6 @@ __device__ __forceinline__ void store_tile_row16(bf16_t* row, bool ok, const f32
 }
 
 
-#ifdef REID_ATTN_TRACE
-static unsigned long long* g_attn_trace = nullptr;
-extern "C" void reid_debug_attn_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; }
-#define ATTN_TRACE(slot) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)item * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ATTN_TRACE(slot) do { } while (0)
-#endif
 // ------------------------------------------------------------------------------------------ forward
 // TWO_PASS (long sequences): the score tiles are NOT kept in registers.  Pass 1 computes them for the row maximum only,
 // pass 2 recomputes each tile, exponentiates it and feeds it straight into the P.V MFMAs.  The 28 extra MFMAs per wave
@@ -153,28 +153,26 @@ extern "C" void reid_debug_attn_trace(void* buf) { g_attn_trace = (unsigned long
 // K/V staging and output stores overlap the other's MFMAs and softmax (a single resident workgroup ran load -> compute ->
 // store strictly in sequence).  Short sequences (text tower, NT <= 3) keep the single pass.
 template <int NT, bool TWO_PASS>   // number of 32-row tiles: S <= 32*NT
-__device__ __forceinline__ void attn_fwd_item(const AttnParams& p, const int item, char* smem) {
+__global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + NT * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = item / p.heads, head = item % p.heads;
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
-    ATTN_TRACE(0);
-#ifdef REID_ATTN_TRACE
-    if (p.trace && threadIdx.x == 0) p.trace[(size_t)item * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-#endif
     stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);
-    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
     const int q0 = wave * 32;
     const int qi = q0 + (lane & 31);
     const int qrow = qi < p.S ? qi : p.S - 1;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = gfrag(qb, p.ld, qrow, 2 * ks, lane);
+    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
     __syncthreads();
-    if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) return;   // wave-uniform; the caller's loop barrier is the next one
+    if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) return;   // wave-uniform; no barrier follows
+
     if (p.dbg == 3) return;
     const FragOff fo = make_frag_off(lane);
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
@@ -222,7 +220,6 @@ __device__ __forceinline__ void attn_fwd_item(const AttnParams& p, const int ite
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (mx == -INFINITY) mx = 0.f;
         const float nmc = -mx * c;
-        ATTN_TRACE(2);                                      // first sweep done (wave 0)
 #pragma unroll 1
         for (int kt = 0; kt < (p.dbg == 2 ? 0 : NT); ++kt) {
             f32x16 t = score_tile(kt);
@@ -268,7 +265,6 @@ __device__ __forceinline__ void attn_fwd_item(const AttnParams& p, const int ite
             }
     }
     l += __shfl_xor(l, 32, 64);
-    ATTN_TRACE(3);                                          // second sweep done (wave 0)
     if (p.dbg >= 1 && l != 12345.678f) return;
     {
         const float inv = 1.0f / l;
@@ -276,24 +272,6 @@ __device__ __forceinline__ void attn_fwd_item(const AttnParams& p, const int ite
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) store_tile_row16(orow + dt * 32, qi < p.S, ot[dt], inv, lane);
         if (qi < p.S && p.lse && lane < 32) p.lse[((size_t)seq * p.heads + head) * p.S + qi] = mx * 0.125f + logf(l);
-    }
-    ATTN_TRACE(4);                                          // stores issued (wave 0)
-#ifdef REID_ATTN_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ATTN_TRACE(5);                                          // stores acknowledged (wave 0)
-#endif
-}
-
-// PERSISTENT workgroups (r02): the grid is what the chip holds at once and every workgroup walks (sequence, head) items with a
-// grid stride.  With one item per workgroup (3072 workgroups of ~12 us) a CU slot sat empty 2.4 us between a workgroup's end and its
-// successor's start and held 1.44 resident workgroups on average instead of 2 (per-workgroup timestamps, tools/exp_attn_trace.py).
-template <int NT, bool TWO_PASS>
-__global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_items = p.n_seq * p.heads;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        attn_fwd_item<NT, TWO_PASS>(p, item, smem);
-        __syncthreads();                                    // every wave is done with K, V before the next item overwrites them
     }
 }
 
@@ -330,13 +308,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 //  tiles -- 120 VGPRs, two workgroups per CU, S recomputed (20 instead of 16 MFMAs per tile pair) -- was 0.2 ms per step
 //  SLOWER: occupancy is not what holds this kernel back.)
 template <int NT>
-__device__ __forceinline__ void attn_bwd_dkv_item(const AttnParams& p, const int item, char* smem) {
+__global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* Gs = smem + NT * 32 * 128;                 // dO
     float* rowc = (float*)(smem + 2 * NT * 32 * 128);   // [2][NT*32]: lse, delta
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = item / p.heads, head = item % p.heads;
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
     const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
@@ -427,22 +406,13 @@ __device__ __forceinline__ void attn_bwd_dkv_item(const AttnParams& p, const int
 // Wave w owns query tile w (queries on the lane).  S^T = K.Q^T and dP^T = V.dO^T land as
 // [key rows (regs) x query columns (lanes)]; dQ^T += K^T.dS^T.
 template <int NT>
-__global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams p) {      // persistent, as the forward kernel
+__global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_items = p.n_seq * p.heads;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        attn_bwd_dkv_item<NT>(p, item, smem);
-        __syncthreads();
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void attn_bwd_dq_item(const AttnParams& p, const int item, char* smem) {
     char* Ks = smem;
     char* Vs = smem + NT * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = item / p.heads, head = item % p.heads;
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int d = p.heads * 64;
     const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
     const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
@@ -521,34 +491,12 @@ __device__ __forceinline__ void attn_bwd_dq_item(const AttnParams& p, const int 
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p) {       // persistent, as the forward kernel
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_items = p.n_seq * p.heads;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        attn_bwd_dq_item<NT>(p, item, smem);
-        __syncthreads();
-    }
-}
-
-// grid of a persistent launch: `per_cu` workgroups per CU (what the kernel's registers and LDS allow to be resident; a larger grid
-// is harmless -- the surplus workgroups start when the first ones finish and find fewer items left), at most one per item.
-// REID_ATTN_PERSIST=0 restores one workgroup per item; > 0 overrides per_cu.
-inline int persistent_grid(int n_items, int per_cu) {
-    const int k = reid_knob(KNOB_ATTN_PERSIST);
-    if (k == 0) return n_items;
-    if (k > 0) per_cu = k;
-    const long g = (long)per_cu * reid_num_cus();
-    return (int)(g < n_items ? g : n_items);
-}
-
-template <int NT>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * NT * 32 * 128;
     static bool attr_set = false;
     constexpr bool TP = NT >= 4;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    const int grid = persistent_grid(p.n_seq * p.heads, NT >= 4 ? 2 : 8);
-    hipLaunchKernelGGL((attn_fwd_kernel<NT, TP>), dim3(grid), dim3(NT * 64), LDS, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<NT, TP>), dim3(p.n_seq * p.heads), dim3(NT * 64), LDS, s, p);
     REID_CHECK_LAUNCH("reid_attn_fwd");
     return REID_OK;
 }
@@ -566,11 +514,9 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
     const long rows = (long)p.n_seq * p.S;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(delta)");
-    const int grid1 = persistent_grid(p.n_seq * p.heads, NT >= 4 ? 1 : 8);       // dK/dV: 160 VGPRs, one 7-wave workgroup per CU
-    const int grid2 = persistent_grid(p.n_seq * p.heads, NT >= 4 ? 2 : 8);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(grid1), dim3(NT * 64), LDS1, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS1, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(dkv)");
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3(grid2), dim3(NT * 64), LDS2, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS2, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(dq)");
     return REID_OK;
 }
@@ -600,10 +546,7 @@ extern "C" int reid_attn_fwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     int rc = check_common("reid_attn_fwd", qkv, ld, n_seq, S, heads);
     if (rc) return rc;
     REID_CHECK_ARG(out && ldo >= heads * 64 && ldo % 4 == 0, "reid_attn_fwd: out/ldo");
-    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0, nullptr};
-#ifdef REID_ATTN_TRACE
-    p.trace = g_attn_trace;
-#endif
+    AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, lse, nullptr, nullptr, 0, nullptr, n_seq, S, heads, causal, q_tiles, 0};
     if (reid_knob(KNOB_ATTN_DBG) > 0) p.dbg = reid_knob(KNOB_ATTN_DBG);
     DISPATCH_NT((S + 31) / 32, launch_fwd, p, (hipStream_t)stream)
 }
@@ -616,6 +559,6 @@ extern "C" int reid_attn_bwd(const void* qkv, int32_t ld, const uint8_t* key_mas
     REID_CHECK_ARG(out && dout && lse && dqkv && delta_ws, "reid_attn_bwd: null pointer");
     REID_CHECK_ARG(ldo >= heads * 64 && ldo % 8 == 0 && lddqkv >= 3 * heads * 64 && lddqkv % 4 == 0, "reid_attn_bwd: ldo/lddqkv");
     AttnParams p{(const bf16_t*)qkv, ld, key_mask, (bf16_t*)out, ldo, (float*)lse, (const bf16_t*)dout, (bf16_t*)dqkv, lddqkv,
-                 delta_ws, n_seq, S, heads, causal, q_tiles, 0, nullptr};
+                 delta_ws, n_seq, S, heads, causal, q_tiles, 0};
     DISPATCH_NT((S + 31) / 32, launch_bwd, p, (hipStream_t)stream)
 }

@@ -131,6 +131,7 @@ class Engine:
         self.text_backward_ready = True
         self._text_packed = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
+        self.tn_defer = os.environ.get('REID_TN_DEFER', '0') == '1'    # experiment: MLP / out-proj dA, dB reductions held back until the attention backward
         self.cls_prune = os.environ.get('REID_CLS_PRUNE', '1') != '0'
         self.W = {}
 
@@ -400,10 +401,20 @@ class Engine:
         main = torch.cuda.current_stream(dev)
         side = self._side_stream() if self.overlap_tn else None
 
-        def fork(*calls):
+        pending = []
+        defer = self.tn_defer and side is not None
+
+        def fork(*calls, flush=False):
             if side is None:
                 for c in calls:
                     ops.gemm_tn(*c, beta=1.0)
+                return
+            if defer and not flush:                         # hold the MLP / out-projection reductions back until the attention backward
+                pending.extend(calls)
+                return
+            calls = tuple(pending) + calls
+            pending.clear()
+            if not calls:
                 return
             ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
             with torch.cuda.stream(side):
@@ -458,6 +469,8 @@ class Engine:
                 do.zero_(); do.index_copy_(0, idxl, dor)
                 dxm.zero_(); dxm.index_copy_(0, idxl, dxmr)
             # ---- attention
+            if defer:
+                fork(flush=True)
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads, q_tiles=1 if c else 0)
             # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
             bT = pk(l, 'qkv', 'BT')                         # [Rp, 3d]
@@ -465,7 +478,7 @@ class Engine:
             for g in range(3):
                 ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
             fork(*[(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d]) for g in range(3)],
-                 (Uq, s['h'], gA(l, 'qkv')))
+                 (Uq, s['h'], gA(l, 'qkv')), flush=True)
             if l == 0 and not want_dense:
                 # nothing below layer 0 trains under the default freeze: the gradient of the embedded sequence (dX of the
                 # q|k|v projection and the LN1 backward) would be computed only to be thrown away

@@ -22,18 +22,6 @@ def knob(name, v):
 for dbg in (3, 2, 1, 0):
     knob('ATTN_DBG', dbg if dbg else -1)
     print('dbg', dbg, round(timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)), 1), 'us', flush=True)
-ref = o.clone()
-for persist in (0, 1, 2, 3, 4):
-    knob('ATTN_PERSIST', persist)
-    res = [timeit(lambda: ops.attn_fwd(qkv, o, lse, n_img, S, heads)) for _ in range(3)]
-    print(('persistent x%d' % persist) if persist else 'one workgroup per item', round(min(res), 1), 'us  equal', bool(torch.equal(o, ref)), flush=True)
-knob('ATTN_PERSIST', -1)
-# backward
-do = (torch.randn(M, d, device='cuda', generator=g)).to(T16); dqkv = torch.empty(M, 3 * d, device='cuda', dtype=T16)
-delta = torch.empty(n_img, heads, S, device='cuda')
-ops.attn_bwd(qkv, o, do, lse, dqkv, delta, n_img, S, heads); refd = dqkv.clone()
-for persist in (0, 1, 2, 3):
-    knob('ATTN_PERSIST', persist)
-    res = [timeit(lambda: ops.attn_bwd(qkv, o, do, lse, dqkv, delta, n_img, S, heads)) for _ in range(3)]
-    print('bwd (delta + dkv + dq):', ('persistent x%d' % persist) if persist else 'one workgroup per item', round(min(res), 1), 'us  equal', bool(torch.equal(dqkv, refd)), flush=True)
-knob('ATTN_PERSIST', -1)
+# (the persistent-workgroup / stagger / split variants this script also timed in r02 live in profiles/r02_attn_persistent_experiment.patch;
+#  results: profiles/r02_attn_persistent.log, r02_attn_stagger_split.log)
+knob('ATTN_DBG', -1)

@@ -1,4 +1,5 @@
-"""Per-workgroup timeline of attn_fwd_kernel<7,true> (library built with -DREID_ATTN_TRACE): s_memrealtime (100 MHz) at the phase
+"""(Needs profiles/r02_attn_persistent_experiment.patch applied: the trace hooks are part of that experiment, not of the shipped kernels.)
+Per-workgroup timeline of attn_fwd_kernel<7,true> (library built with -DREID_ATTN_TRACE): s_memrealtime (100 MHz) at the phase
 boundaries of every workgroup + its CU, for 256 images x 12 heads.  Prints phase durations and how the workgroups of one CU overlap."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
