@@ -235,13 +235,14 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
     if constexpr (EPI == EPI_RES32) {
         const uint32_t col = (uint32_t)(n_base + 4 * fq);
         char* C = (char*)p.C; const char* R = (const char*)p.R;
-        constexpr int HG = TM / 2;                                                   // 16-row groups per half
+        constexpr int HG = (TM + 1) / 2;                                             // 16-row groups per half (the second may be one short)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 r[HG][TN];
             float rs[HG];
 #pragma unroll
             for (int ii = 0; ii < HG; ++ii) {
+                if (half * HG + ii >= TM) break;
                 const int m = m_base + 16 * (half * HG + ii) + frow;
                 const int mc = m < p.M ? m : p.M - 1;
                 const uint32_t ro = ((uint32_t)mc * (uint32_t)p.ldr + col) * 4u;
@@ -252,6 +253,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
             for (int ii = 0; ii < HG; ++ii) {
                 const int i = half * HG + ii;
+                if (i >= TM) break;
                 const int m = m_base + 16 * i + frow;
                 const bool ok = m < p.M;
                 const uint32_t co = ((uint32_t)(ok ? m : p.M - 1) * (uint32_t)p.ldc + col) * 4u;
@@ -383,8 +385,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
 }
 
 // 256 x 256 tile with the wave-row ping-pong K loop of gemm_core.h (mainloop_pp); epilogue = the same register-direct code
-template <int EPI>
+template <int EPI, int BM = 256>
 __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p) {
+    using PC = PPCfg<BM, 256>;
+    constexpr int TM = PC::TM, RW = PC::RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -406,29 +410,29 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * BM, n0 = tn * 256;
     const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
-    f32x4 acc[4][8];
-    if constexpr (EPI == EPI_GENERIC) init_acc<8, 4>(p, acc, n0 + wn * 64, lane);
-    else if constexpr (EPI == EPI_RES32) init_acc_m<8, 4, 0>(p, acc, n0 + wn * 64, lane);
-    else init_acc_m<8, 4, 1>(p, acc, n0 + wn * 64, lane);
+    f32x4 acc[4][TM];
+    if constexpr (EPI == EPI_GENERIC) init_acc<TM, 4>(p, acc, n0 + wn * 64, lane);
+    else if constexpr (EPI == EPI_RES32) init_acc_m<TM, 4, 0>(p, acc, n0 + wn * 64, lane);
+    else init_acc_m<TM, 4, 1>(p, acc, n0 + wn * 64, lane);
 #ifdef REID_GEMM_ABLATIONS                                  // K-loop anatomy builds (profiles/r02_gemm_variants10*.log); not in the shipped library
-    if (EPI == EPI_PLAIN16 && p.dbg >= 16) {
+    if (EPI == EPI_PLAIN16 && BM == 256 && p.dbg >= 16) {
         switch (p.dbg - 16) {
-            case 1: mainloop_pp<256, 256, 1>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 2: mainloop_pp<256, 256, 2>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 3: mainloop_pp<256, 256, 3>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 4: mainloop_pp<256, 256, 4>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 6: mainloop_pp<256, 256, 6>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 11: mainloop_pp<256, 256, 11>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 1: mainloop_pp<BM, 256, 1>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 2: mainloop_pp<BM, 256, 2>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 3: mainloop_pp<BM, 256, 3>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 4: mainloop_pp<BM, 256, 4>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 6: mainloop_pp<BM, 256, 6>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 11: mainloop_pp<BM, 256, 11>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
             default: break;
         }
         if (acc[0][0][0] != 1234.5f) return;
     }
 #endif
     if (p.dbg != 4)
-        mainloop_pp<256, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
+        mainloop_pp<BM, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
     GEMM_TRACE(1);
     if (p.dbg == 1) return;
     if constexpr (EPI == EPI_MULAUX) {
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
         // kept a workgroup 8.5 us in this epilogue (per-workgroup trace, tools/exp_gemm_trace.py), most of it waiting for those reads.
         __syncthreads();                                     // every wave has left the K loop's last fragment reads
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < BM / 16; ++q) {
             const int rp = q * 8 + wave;                     // row pair
             const int row = 2 * rp + (lane >> 5);
             const int c = lane & 31;                         // destination chunk position; it holds source chunk c ^ (row & 15)
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        store_tile_fast<8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem, wm * 128, wn * 8);
+        store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, smem, wm * RW, wn * 8);
         GEMM_TRACE(2);
 #ifdef REID_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -455,8 +459,8 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
 #endif
         return;
     }
-    if constexpr (EPI == EPI_GENERIC) store_tile<8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-    else store_tile_fast<8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    if constexpr (EPI == EPI_GENERIC) store_tile<TM, 4>(p, acc, m0 + wm * RW, n0 + wn * 64, lane);
+    else store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane);
     GEMM_TRACE(2);
 #ifdef REID_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -468,35 +472,49 @@ static unsigned long long* g_gemm_trace = nullptr;
 extern "C" void reid_debug_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; }
 #endif
 
-template <int EPI>
+template <int EPI, int BM>
 int launch_pp_e(GemmParams& p, hipStream_t s) {
-    using C = PPCfg<256, 256>;
+    using C = PPCfg<BM, 256>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)mer_gemm_pp_kernel<EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(mer_gemm_pp_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((mer_gemm_pp_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_mer_gemm");
     return REID_OK;
 }
-int launch_pp(GemmParams& p, hipStream_t s) {
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
+// Tile height of the ping-pong kernel: 224 rows when that needs no more rounds of 256 workgroups than 256 rows do (each round is then 7/8
+// as long: fc2 267 -> 246 us, fc1 backward 223 -> 206 us, q|k|v backward 199 -> 190 us at 50 432 rows, N = 768); with an extra round the
+// per-tile costs (first operands, epilogue) outweigh the shorter tiles (N = 3072: 318 -> 333 us).  REID_GEMM_TILE=12 / 14 force 256 / 224.
+static int pick_pp_bm(const GemmParams& p, int tile_knob) {
+    if (tile_knob == 12) return 256;
+    if (tile_knob == 14) return 224;
+    const long cus = reid_num_cus();
+    const long tn = p.N / 256;
+    const long t256 = ((p.M + 255) / 256) * tn, t224 = ((p.M + 223) / 224) * tn;
+    return (t224 + cus - 1) / cus <= (t256 + cus - 1) / cus ? 224 : 256;
+}
+int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 256);
+    const int bm = p.epi == EPI_GENERIC ? 256 : pick_pp_bm(p, tile_knob);     // (the generic epilogue is only built for the 256-row tile)
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + 255) / 256;
     p.stagger = reid_knob(KNOB_GEMM_STAGGER) > 0 ? reid_knob(KNOB_GEMM_STAGGER) : 0;
 #ifdef REID_GEMM_TRACE
     p.trace = g_gemm_trace;
 #endif
+#define REID_PP_CASE(E) case E: return bm == 224 ? launch_pp_e<E, 224>(p, s) : launch_pp_e<E, 256>(p, s);
     switch (p.epi) {
-        case EPI_PLAIN16: return launch_pp_e<EPI_PLAIN16>(p, s);
-        case EPI_RES32: return launch_pp_e<EPI_RES32>(p, s);
-        case EPI_GELU2: return launch_pp_e<EPI_GELU2>(p, s);
-        case EPI_DGELU: return launch_pp_e<EPI_DGELU>(p, s);
-        case EPI_GELU2D: return launch_pp_e<EPI_GELU2D>(p, s);
-        case EPI_MULAUX: return launch_pp_e<EPI_MULAUX>(p, s);
-        default: return launch_pp_e<EPI_GENERIC>(p, s);
+        REID_PP_CASE(EPI_PLAIN16)
+        REID_PP_CASE(EPI_RES32)
+        REID_PP_CASE(EPI_GELU2)
+        REID_PP_CASE(EPI_DGELU)
+        REID_PP_CASE(EPI_GELU2D)
+        REID_PP_CASE(EPI_MULAUX)
+        default: return launch_pp_e<EPI_GENERIC, 256>(p, s);
     }
+#undef REID_PP_CASE
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -624,8 +642,8 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
         const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
         const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();
-        if (pp_ok && (tile == 12 || (tile == 0 && pp_shape && reid_knob(KNOB_GEMM_EPI) != 0 && pick_epilogue(p, 256) != EPI_GENERIC)))
-            return launch_pp(p, s);
+        if (pp_ok && (tile == 12 || tile == 14 || (tile == 0 && pp_shape && reid_knob(KNOB_GEMM_EPI) != 0 && pick_epilogue(p, 256) != EPI_GENERIC)))
+            return launch_pp(p, s, tile);
     }
     // Default from same-process A/B runs of the seven ViT GEMM variants (tools/bench_gemm_variants.py, r01): 128x128x64
     // tiles, 4 waves, 64 KiB of LDS -> TWO workgroups per CU.  With the register-direct epilogue its K loop runs as fast

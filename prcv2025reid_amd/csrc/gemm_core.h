@@ -201,9 +201,15 @@ __device__ __forceinline__ void mainloop(const bf16_t* __restrict__ A, int lda, 
 // 1667 us per layer; its 12-read phase and the short prefetch distance both showed as matrix-pipe idle time.)
 template <int BM, int BN>
 struct PPCfg {
-    static_assert(BM == 256 && BN == 256, "ping-pong loop is written for the 256 x 256 tile");
-    static constexpr int NW = 8, NT = 512, WM = 2, WN = 4, TM = 8, TN = 4;
-    static constexpr int HALF_BYTES = 128 * 128;                 // 16 KiB
+    // BM = 224 (wave rows of 112 = 64 + 48 activation rows): same loop, chosen where it packs the chip's 256 CUs better -- M = 50 432,
+    // N = 768 is 591 tiles of 256 x 256 = 2.31 rounds (three rounds, 77 % full) but 678 tiles of 224 x 256 = 2.65 rounds of 7/8 the size.
+    static_assert((BM == 256 || BM == 224) && BN == 256, "ping-pong loop is written for 256 x 256 and 224 x 256 tiles");
+    static constexpr int NW = 8, NT = 512, WM = 2, WN = 4, TN = 4;
+    static constexpr int RW = BM / 2;                            // activation rows per wave row
+    static constexpr int TM = RW / 16;                           // 16-row sub-tiles per wave: 8 or 7
+    static constexpr int TM0 = 4, TM1 = TM - 4;                  // sub-tiles of the two MFMA phases
+    static constexpr int A_INSTR = RW / 8;                       // LDS-DMA instructions per activation half-tile (4 waves share them)
+    static constexpr int HALF_BYTES = 128 * 128;                 // 16 KiB slots
     static constexpr int BUF_BYTES = 4 * HALF_BYTES;             // SA0 | SA1 | SB0 | SB1
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
@@ -216,7 +222,7 @@ __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcn
 template <int BM, int BN, int ABL = 0>
 __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                             const bf16_t* __restrict__ A2, int lda2, const bf16_t* __restrict__ B2, int ldb2,
-                                            int M, int N, int K, int K2, int m0, int n0, char* smem, f32x4 (&acc)[4][8], bool perm_b) {
+                                            int M, int N, int K, int K2, int m0, int n0, char* smem, f32x4 (&acc)[4][PPCfg<BM, BN>::TM], bool perm_b) {
     using C = PPCfg<BM, BN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -234,10 +240,12 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (j * 4 + wn) * 8 + rl;
-        int ga = m0 + 128 * wm + r;
+        int ga = m0 + C::RW * wm + r;
         ga = ga < M - 1 ? ga : M - 1;
         offA[j] = (uint32_t)ga * (uint32_t)lda * 2u + (uint32_t)swz(r, cl) * 16u;
     }
+    // instruction j of a wave covers half-tile rows (4 j + wn) * 8 ...: the 224-row tile has 14 such blocks, waves 2 and 3 skip j = 3
+    const bool a_last = 12 + wn < C::A_INSTR;                                  // wave-uniform
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -254,8 +262,10 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
         char* dst = smem + buf * C::BUF_BYTES + wm * C::HALF_BYTES;
         const char* src = (const char*)A + (size_t)t * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 3; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[j]), (lptr_t)(dst + (j * 4 + wn) * 8 * 128), 16, 0, 0);
+        if (C::A_INSTR == 16 || a_last)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[3]), (lptr_t)(dst + (12 + wn) * 8 * 128), 16, 0, 0);
     };
     auto stage_b = [&](int t, int buf) {
         if constexpr (ABL & 1) return;
@@ -273,8 +283,9 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
         const int k2 = (t - nk) << 5;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (j == 3 && C::A_INSTR != 16 && !a_last) break;
             const int r = (j * 4 + wn) * 8 + rl;
-            int ga = m0 + 128 * wm + r;
+            int ga = m0 + C::RW * wm + r;
             ga = ga < M - 1 ? ga : M - 1;
             const bf16_t* g = A2 + (size_t)ga * lda2 + k2 + (swz(r, cl) & 3) * 8;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (j * 4 + wn) * 8 * 128), 16, 0, 0);
@@ -318,9 +329,11 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
         if constexpr (ABL & 2) return;
         const char* base = smem + buf * C::BUF_BYTES + a_base + a * 64 * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            if (a == 1 && i >= C::TM1) break;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) af[i][ks] = *(const bf16x8*)(base + i * 16 * 128 + foff[ks]);
+        }
     };
     auto read_b = [&](int buf, auto nks_c) {
         constexpr int NKS = decltype(nks_c)::value;
@@ -344,7 +357,7 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < (a == 0 ? C::TM0 : C::TM1); ++i)
                         acc[2 * b + j][4 * a + i] = mfma16(bfr[b][j][ks], af[i][ks], acc[2 * b + j][4 * a + i]);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -369,7 +382,11 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
 
     // prologue: K-tiles 0 and 1 in the steady-state issue order
     stage_b_any(0, 0); stage_a_any(0, 0);
-    if (nt > 1) { stage_b_any(1, 1); stage_a_any(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } else { pp_wait_vm0(); }
+    if (nt > 1) {
+        stage_b_any(1, 1); stage_a_any(1, 1);
+        if (C::A_INSTR == 16 || a_last) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K-tile 1 = this wave's last 8 (or 7) instructions
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else { pp_wait_vm0(); }
     bar();
     if (wm == 1) bar();                                                      // wave row 1 runs one barrier behind
     int cur = 0;

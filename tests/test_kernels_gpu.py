@@ -150,9 +150,9 @@ def test_gemm_epilogues(ops):
     assert rel_err(xr[:, 1:], ref) < 2e-5 and float(xr[:, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('tile', [0, 12, 3])
+@pytest.mark.parametrize('tile', [0, 12, 14, 3])
 def test_gemm_large_tile_paths(ops, tile):
-    """The 256 x 256 ping-pong tile (12), the 128 x 128 tile (3) and the
+    """The 256 x 256 and 224 x 256 ping-pong tiles (12, 14), the 128 x 128 tile (3) and the
     default dispatch (0) on the training-size shapes they serve, with every lean epilogue and the LoRA K extension; ragged M."""
     from prcv2025reid_amd import _lib
     g = torch.Generator(device='cuda').manual_seed(77 + tile)
