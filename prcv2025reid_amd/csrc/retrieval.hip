@@ -661,6 +661,71 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restric
     }
 }
 
+__host__ __device__ inline int merge_survivor_cap(int n, int k) { const int c = 16 * k * k + 64; return c < n ? c : n; }
+
+// One workgroup per query merges the workgroups' lists, each sorted best-first.  ALL entries come into LDS with one round of
+// coalesced 16-byte loads (r01 walked the lists in global memory: head, then entry after entry, each a dependent L2 round trip --
+// 16.6 us for 80 KB, a fifth of a single-query call; this form 10.9 us, the wave-wide rank sorts of ~1.2 us each being what is left;
+// 1024 threads for the staging: 12.8 us).  In LDS: the k-th best of 64 list heads (the best head each lane sees) is a
+// bar no result can rank behind, and only lists whose head clears it can hold entries that do: one pass over the lists leaves a
+// few dozen survivors (at most 16 k^2: fewer than k lanes have a head above the bar, each lane stands for <= 16 lists of k entries)
+// in a second LDS region, from which one wave takes the k best.  Used when both regions fit the LDS (k <= 12 at the default list
+// budget); otherwise the global-memory form below.
+__global__ __launch_bounds__(256) void stream_merge_lds_kernel(const float* __restrict__ part_score, const int32_t* __restrict__ part_idx,
+                                                           int groups, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    extern __shared__ __attribute__((aligned(16))) char smm[];
+    const int n = groups * k;
+    const int n4 = (n + 3) & ~3;
+    float* sc = (float*)smm;                       // [n4] all scores
+    int32_t* ix = (int32_t*)(sc + n4);             // [n4] all indices
+    const int cap = merge_survivor_cap(n, k);
+    float* ssc = (float*)(ix + n4);                // [cap] survivors
+    int32_t* six = (int32_t*)(ssc + cap);
+    __shared__ int lcnt;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* ps = part_score + (size_t)q * n;
+    const int32_t* pi = part_idx + (size_t)q * n;
+    if (tid == 0) lcnt = 0;
+    if ((n & 3) == 0 && ((((size_t)q * n) & 3) == 0)) {
+        for (int i = tid * 4; i < n; i += 1024) {
+            *(f32x4*)(sc + i) = *(const f32x4*)(ps + i);
+            *(int4*)(ix + i) = *(const int4*)(pi + i);
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) { sc[i] = ps[i]; ix[i] = pi[i]; }
+    }
+    __syncthreads();
+    // every wave derives the bar for itself (no cross-wave exchange)
+    LaneList hb{-INFINITY, -1};
+    for (int g = lane; g < groups; g += 64) {
+        const float hs = sc[g * k]; const int hi = ix[g * k];
+        if (hi >= 0 && (hb.i < 0 || ranks_before(hs, hi, hb.s, hb.i))) hb = LaneList{hs, hi};
+    }
+    const int nh = lanelist_sort(hb, 64, lane);
+    float bar_s = -INFINITY; int bar_i = 0x7fffffff;                // fewer than k non-empty lanes: no bar
+    if (nh >= k) {
+        bar_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hb.s), k - 1));
+        bar_i = __builtin_amdgcn_readlane(hb.i, k - 1);
+    }
+    for (int g = tid; g < groups; g += 256) {
+        const float* ls = sc + g * k; const int32_t* li = ix + g * k;
+        for (int c = 0; c < k; ++c) {                               // lists are sorted: stop at the first entry behind the bar
+            const float s = ls[c]; const int gi = li[c];
+            if (gi < 0 || ranks_before(bar_s, bar_i, s, gi)) break;
+            const int pos = atomicAdd(&lcnt, 1);
+            ssc[pos] = s; six[pos] = gi;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    LaneList e;
+    const int real = wave_select_lds(ssc, six, lcnt, k, lane, e);
+    if (lane < k) {
+        out_idx[(size_t)q * k + lane] = lane < real ? e.i : -1;
+        out_score[(size_t)q * k + lane] = lane < real ? e.s : -INFINITY;
+    }
+}
+
 // One workgroup per query merges the workgroups' lists, each sorted best-first.  The k-th best of 64 list heads (the best head
 // each lane sees) is a bar no result can rank behind, and only lists whose head clears it can hold entries that do: one pass
 // over the lists leaves a few dozen survivors in LDS (n in the worst case: the buffer holds them all), from which one wave
@@ -731,7 +796,11 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
     float* ps = (float*)ws;
     int32_t* pi = (int32_t*)(ps + (size_t)SQ * groups * k);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)stream_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LIST_BUDGET * 8); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)stream_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LIST_BUDGET * 8);
+        (void)hipFuncSetAttribute((const void*)stream_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr = true;
+    }
     for (int q0 = 0; q0 < Nq; q0 += SQ) {
         const int nq = Nq - q0 < SQ ? Nq - q0 : SQ;
         const float* Q = Qf + (size_t)q0 * D;
@@ -749,8 +818,14 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
 #undef REID_STREAM_LAUNCH
 #undef REID_STREAM_LAUNCH1
         REID_CHECK_LAUNCH("reid_cosine_topk_stream(scan)");
-        hipLaunchKernelGGL(stream_merge_kernel, dim3(nq), dim3(256), (size_t)groups * k * 8, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
-                           out_score + (size_t)q0 * k);
+        const int n_ent = groups * k;
+        const size_t lds_fast = (size_t)((n_ent + 3) & ~3) * 8 + (size_t)merge_survivor_cap(n_ent, k) * 8;
+        if (lds_fast <= 160 * 1024 - 64)
+            hipLaunchKernelGGL(stream_merge_lds_kernel, dim3(nq), dim3(256), lds_fast, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
+                               out_score + (size_t)q0 * k);
+        else
+            hipLaunchKernelGGL(stream_merge_kernel, dim3(nq), dim3(256), (size_t)groups * k * 8, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
+                               out_score + (size_t)q0 * k);
         REID_CHECK_LAUNCH("reid_cosine_topk_stream(merge)");
     }
     return REID_OK;
