@@ -17,7 +17,7 @@ void reid_set_error(const char* fmt, ...);
 // environment (REID_<NAME>) on first use and changed afterwards only through reid_set_knob() -- no getenv() on the launch path.
 enum reid_knob_id {
     KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI, KNOB_GEMM_STAGGER,
-    KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_SDM_IMPL, KNOB_COUNT
+    KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_STREAM_GROUPS, KNOB_SDM_IMPL, KNOB_COUNT
 };
 int reid_knob(int id);
 int reid_num_cus();   // compute units of the current device (cached)
