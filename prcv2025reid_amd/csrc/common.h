@@ -68,8 +68,17 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return 
 #define REID_T16_EPS 0.00390625f         /* 2u = 2^-8 for bf16 (u = 2^-9) */
 #endif
 
+// two floats -> one dword of the flavor's 16-bit format, converted as a 2-vector: ONE v_cvt_pk_bf16_f32 (the scalar-by-scalar form
+// made hipcc pair the wrong halves and re-interleave them with v_and / v_lshl / two v_or_b32_sdwa per dword)
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef REID_FLAVOR_F16
+typedef _Float16 pk_t16x2 __attribute__((ext_vector_type(2)));
+#else
+typedef __bf16 pk_t16x2 __attribute__((ext_vector_type(2)));
+#endif
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const pk_t16x2 r = __builtin_convertvector(pk_f32x2{lo, hi}, pk_t16x2);
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -107,6 +116,28 @@ __device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {     
     gauss_cdf_pdf(x, c, e);
     g = x * c;
     dg = fmaf(x * 0.39894228040143268f, e, c);
+}
+// The same value / derivative for a PAIR of elements, written on 2-vectors so that the polynomial, the products and the sign
+// handling compile to v_pk_fma_f32 / v_pk_mul_f32 (the lean 16-bit GEMM epilogues are bound by exactly this arithmetic: two waves per
+// SIMD x 128 elements per lane).  cdf = 0.5 + copysign(0.5 - q, x) instead of a compare + select: absolute error <= 6e-8 more than
+// gauss_cdf_pdf (the relative accuracy of the far negative tail is given up: fine for 16-bit outputs, which is where this is used).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_both_x2(f32x2_t x, f32x2_t& g, f32x2_t& dg) {
+    const f32x2_t xs = (x * x) * -0.72134752044448170f;                              // -x^2 log2(e) / 2
+    f32x2_t e; e.x = __builtin_amdgcn_exp2f(xs.x); e.y = __builtin_amdgcn_exp2f(xs.y);
+    f32x2_t z; z.x = __builtin_fabsf(x.x); z.y = __builtin_fabsf(x.y);
+    const f32x2_t den = z * (0.3275911f * 0.70710678118654752f) + 1.0f;
+    f32x2_t t; t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+    f32x2_t poly = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);                // 0.5 erfc: the 0.5 is folded into the coefficients
+    poly = poly * t + (0.5f * 1.421413741f);
+    poly = poly * t + (0.5f * -0.284496736f);
+    poly = poly * t + (0.5f * 0.254829592f);
+    const f32x2_t q = (poly * t) * e;
+    const f32x2_t h = 0.5f - q;
+    f32x2_t sh; sh.x = __builtin_copysignf(h.x, x.x); sh.y = __builtin_copysignf(h.y, x.y);
+    const f32x2_t cdf = sh + 0.5f;
+    g = x * cdf;
+    dg = (x * 0.39894228040143268f) * e + cdf;
 }
 __device__ __forceinline__ float dgelu_erf_f(float x) {
     float c, e;

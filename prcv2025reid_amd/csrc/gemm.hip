@@ -302,11 +302,19 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
                 if constexpr (EPI == EPI_GELU2) {
                     if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2_t gg, dd;
+                        gelu_both_x2(f32x2_t{v[e], v[e + 1]}, gg, dd);
+                        v[e] = gg.x; v[e + 1] = gg.y;
+                    }
                 } else if constexpr (EPI == EPI_GELU2D) {
                     float dv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2_t gg, dd;
+                        gelu_both_x2(f32x2_t{v[e], v[e + 1]}, gg, dd);
+                        v[e] = gg.x; v[e + 1] = gg.y; dv[e] = dd.x; dv[e + 1] = dd.y;
+                    }
                     if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]), pack_bf16x2(dv[4], dv[5]), pack_bf16x2(dv[6], dv[7])};
                 } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
