@@ -647,6 +647,11 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         // 1667 us per layer.  gfx9 counts loads and stores in one in-order vmcnt: the first counted wait of the next tile has to
         // drain the previous tile's C stores, whereas a workgroup that simply ENDS leaves its stores draining under the next
         // workgroup's K loop.  One tile per workgroup already has the store / K-loop overlap the persistent form was after.)
+        // (r02, second attempt, profiles/r02_gemm_experiments3_persistent_queue.patch: persistent workgroups fed from per-XCD atomic
+        // tile counters with one tile of lookahead, the two-phase loop streaming across tile boundaries, register-only epilogues.
+        // Correct (all GEMM tests pass) and 18 % slower over the seven shapes: per-tile traces show K loops of 30.5 us instead of 20.3 us
+        // and 2.8 us between tiles -- hipcc waits vmcnt(0) for the bias loads of the accumulator init and for the queue index, which
+        // drains the prefetch at every tile start, and the loop carries ~40 spilled registers across tile boundaries.)
         const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
         const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
         const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();
