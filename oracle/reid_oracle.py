@@ -281,7 +281,7 @@ def forward(state, arch, images: Optional[Dict[str, torch.Tensor]], tokens: Opti
         B = tokens['input_ids'].shape[0]
     if B is None:
         raise ValueError('cannot determine batch size')
-    raw, sem, fmask = {}, {}, {}
+    raw, fmask = {}, {}
     if images:
         for m, img in images.items():
             if m not in vmods:
@@ -297,7 +297,6 @@ def forward(state, arch, images: Optional[Dict[str, torch.Tensor]], tokens: Opti
                 full = null.expand(B, -1)
                 mask = torch.zeros(B)
             raw[m] = full; fmask[m] = mask
-            sem[m] = sdm_module(full, state) if training else full
     if tokens is not None and tokens['input_ids'].shape[0] > 0:
         tmask = modality_masks.get('text') if modality_masks is not None else None
         tf = encode_text(tokens['input_ids'], tokens.get('attention_mask'), state, arch)
@@ -308,9 +307,16 @@ def forward(state, arch, images: Optional[Dict[str, torch.Tensor]], tokens: Opti
         else:
             tmask = torch.ones(B)
         raw['text'] = tf; fmask['text'] = tmask
-        sem['text'] = sdm_module(tf, state) if training else tf
-    if not sem:
+    if not raw:
         raise ValueError('no modality given')
+    return head(raw, fmask, state, arch, training, moddrop_keep, min_modalities)
+
+
+def head(raw: Dict[str, torch.Tensor], fmask: Dict[str, torch.Tensor], state, arch, training: bool,
+         moddrop_keep: Optional[Dict[str, bool]] = None, min_modalities: int = 1):
+    """Everything of forward() after the encoders (model.py:392-510): SDM module per modality (training only), batch-level
+    modality dropout, fusion, BN-neck.  ``raw`` = per-modality [B, D] features with null tokens already filled in."""
+    sem = {m: (sdm_module(f, state) if training else f) for m, f in raw.items()}
     if training and moddrop_keep is not None and len(sem) > min_modalities:
         kept = [m for m in sem if m == 'vis' or moddrop_keep.get(m, True)]
         if len(kept) >= min_modalities:

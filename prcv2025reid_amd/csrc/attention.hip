@@ -154,6 +154,7 @@ __device__ __forceinline__ void store_tile_row16(bf16_t* row, bool ok, const f32
 // store strictly in sequence).  Short sequences (text tower, NT <= 3) keep the single pass.
 template <int NT, bool TWO_PASS>   // number of 32-row tiles: S <= 32*NT
 __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(const AttnParams p) {
+    REID_T16_ENTER();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + NT * 32 * 128;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
     __syncthreads();
     if (q0 >= p.S || (p.q_tiles > 0 && wave >= p.q_tiles)) return;   // wave-uniform; no barrier follows
 
-    if (p.dbg == 3) return;
+    if (REID_DBG(p) == 3) return;
     const FragOff fo = make_frag_off(lane);
     const uint8_t* km = p.key_mask ? p.key_mask + (size_t)seq * p.S : nullptr;
     const int h4 = 4 * (lane >> 5);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
         if (mx == -INFINITY) mx = 0.f;
         const float nmc = -mx * c;
 #pragma unroll 1
-        for (int kt = 0; kt < (p.dbg == 2 ? 0 : NT); ++kt) {
+        for (int kt = 0; kt < (REID_DBG(p) == 2 ? 0 : NT); ++kt) {
             f32x16 t = score_tile(kt);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
             }
     }
     l += __shfl_xor(l, 32, 64);
-    if (p.dbg >= 1 && l != 12345.678f) return;
+    if (REID_DBG(p) >= 1 && l != 12345.678f) return;
     {
         const float inv = 1.0f / l;
         bf16_t* orow = p.out + ((size_t)seq * p.S + qrow) * p.ldo + head * 64;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
 // delta[seq, head, q] = sum_d dO[q, d] * O[q, d]
 // one wave per token row; a 256-element chunk (4 heads) per instruction: 8-byte loads, 16 lanes per head
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)p.n_seq * p.S) return;
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 //  SLOWER: occupancy is not what holds this kernel back.)
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+    REID_T16_ENTER();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* Gs = smem + NT * 32 * 128;                 // dO
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dkv_kernel(const AttnParams 
 // [key rows (regs) x query columns (lanes)]; dQ^T += K^T.dS^T.
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+    REID_T16_ENTER();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + NT * 32 * 128;
@@ -493,9 +497,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
 template <int NT>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * NT * 32 * 128;
-    static bool attr_set = false;
     constexpr bool TP = NT >= 4;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NT, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    REID_MAX_LDS((attn_fwd_kernel<NT, TP>), LDS);
     hipLaunchKernelGGL((attn_fwd_kernel<NT, TP>), dim3(p.n_seq * p.heads), dim3(NT * 64), LDS, s, p);
     REID_CHECK_LAUNCH("reid_attn_fwd");
     return REID_OK;
@@ -505,12 +508,8 @@ template <int NT>
 int launch_bwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS1 = 2 * NT * 32 * 128 + 2 * NT * 32 * 4;
     constexpr int LDS2 = 2 * NT * 32 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        attr_set = true;
-    }
+    REID_MAX_LDS((attn_bwd_dkv_kernel<NT>), LDS1);
+    REID_MAX_LDS((attn_bwd_dq_kernel<NT>), LDS2);
     const long rows = (long)p.n_seq * p.S;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(delta)");

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short bf16_t;   // 16-bit storage (bf16 or f16 by flavor)
 
-void reid_set_error(const char* fmt, ...);
+__attribute__((visibility("hidden"))) void reid_set_error(const char* fmt, ...);
 
 // Experiment knobs (tile choice, early-exit builds, pipeline parameters): ONE cached table per process, filled from the
 // environment (REID_<NAME>) on first use and changed afterwards only through reid_set_knob() -- no getenv() on the launch path.
@@ -19,8 +19,17 @@ enum reid_knob_id {
     KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI, KNOB_GEMM_STAGGER,
     KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_STREAM_GROUPS, KNOB_SDM_IMPL, KNOB_COUNT
 };
-int reid_knob(int id);
-int reid_num_cus();   // compute units of the current device (cached)
+// (internal C++ symbols of the library: hidden, only the extern "C" entry points of include/reid_hip.h are exported)
+__attribute__((visibility("hidden"))) int reid_knob(int id);
+__attribute__((visibility("hidden"))) int reid_num_cus();   // compute units of the current device (cached)
+// The *_DBG knobs switch kernels into timing-experiment modes that skip work (WRONG results).  They exist only in builds made with
+// -DREID_EXPERIMENTS (tools/): in the shipped library REID_DBG(p) is the constant 0 -- the early exits are compiled out -- the
+// REID_*_DBG environment variables are ignored and reid_set_knob() refuses those names.
+#ifdef REID_EXPERIMENTS
+#define REID_DBG(p) ((p).dbg)
+#else
+#define REID_DBG(p) 0
+#endif
 
 #define REID_CHECK_ARG(cond, ...)                     \
     do {                                              \
@@ -28,6 +37,37 @@ int reid_num_cus();   // compute units of the current device (cached)
             reid_set_error(__VA_ARGS__);              \
             return REID_ERR_ARG;                      \
         }                                             \
+    } while (0)
+
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute is per device: remembered per (call site = kernel instance,
+// device) in a bit mask, so a process that later uses a second GPU sets it there too; thread-safe (the call is idempotent, the mask
+// atomic); the return code is checked.
+static inline hipError_t reid_max_dyn_lds(const void* fn, int bytes, unsigned* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 32 && ((__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) >> dev) & 1u)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 32) __atomic_fetch_or(done_mask, 1u << dev, __ATOMIC_RELEASE);
+    return e;
+}
+#define REID_MAX_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                         \
+        static unsigned lds_done_ = 0;                                                                           \
+        const hipError_t le_ = reid_max_dyn_lds((const void*)(kernel), (int)(bytes), &lds_done_);                \
+        if (le_ != hipSuccess) {                                                                                 \
+            reid_set_error("hipFuncSetAttribute(%s, dynamic LDS %d): %s", #kernel, (int)(bytes), hipGetErrorString(le_)); \
+            return REID_ERR_LAUNCH;                                                                              \
+        }                                                                                                        \
+    } while (0)
+
+#define REID_CHECK_HIP(call, what)                                                     \
+    do {                                                                               \
+        const hipError_t he_ = (call);                                                 \
+        if (he_ != hipSuccess) {                                                       \
+            reid_set_error("%s: %s", what, hipGetErrorString(he_));                    \
+            return REID_ERR_LAUNCH;                                                    \
+        }                                                                              \
     } while (0)
 
 #define REID_CHECK_LAUNCH(name)                                                        \
@@ -53,6 +93,10 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
+// Range safety: MODE.FP16_OVFL (hardware mode bit 23, per wave) makes every conversion to IEEE half CLAMP a finite value that
+// overflows to +-65504 instead of producing an infinity; true infinities and NaNs pass through unchanged, so a diverged run is still
+// seen by the gradient sanitiser.  Set once at the entry of every kernel that stores 16-bit values.
+#define REID_T16_ENTER() __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1)
 #define REID_FLAVOR_ID 1
 #define REID_T16_EPS 0.0009765625f       /* 2u = 2^-10: bound of |q~.g~ - q.g| for unit vectors rounded to f16 (u = 2^-11) */
 #else
@@ -64,6 +108,7 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+#define REID_T16_ENTER() do { } while (0)      /* bf16 has fp32's exponent range */
 #define REID_FLAVOR_ID 0
 #define REID_T16_EPS 0.00390625f         /* 2u = 2^-8 for bf16 (u = 2^-9) */
 #endif

@@ -362,6 +362,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN]
 
 template <int BM, int BN, int WM, int WN, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmParams p) {
+    REID_T16_ENTER();
     using C = Cfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -381,13 +382,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     if constexpr (EPI == EPI_GENERIC) init_acc<C::TM, C::TN>(p, acc, n0 + wn * (BN / WN), lane);
     else if constexpr (EPI == EPI_RES32) init_acc_m<C::TM, C::TN, 0>(p, acc, n0 + wn * (BN / WN), lane);
     else init_acc_m<C::TM, C::TN, 1>(p, acc, n0 + wn * (BN / WN), lane);
-    if (p.dbg != 4)
+    if (REID_DBG(p) != 4)
         mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
                                  p.perm_b != 0);
 
     // ------------------------------------------------------------------ epilogue (registers -> global, no LDS)
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    if (p.dbg == 1) return;
+    if (REID_DBG(p) == 1) return;
     if constexpr (EPI == EPI_GENERIC) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
     else store_tile_fast<C::TM, C::TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
 // 256 x 256 tile with the wave-row ping-pong K loop of gemm_core.h (mainloop_pp); epilogue = the same register-direct code
 template <int EPI, int BM = 256>
 __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p) {
+    REID_T16_ENTER();
     using PC = PPCfg<BM, 256>;
     constexpr int TM = PC::TM, RW = PC::RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     else if constexpr (EPI == EPI_RES32) init_acc_m<TM, 4, 0>(p, acc, n0 + wn * 64, lane);
     else init_acc_m<TM, 4, 1>(p, acc, n0 + wn * 64, lane);
 #ifdef REID_GEMM_ABLATIONS                                  // K-loop anatomy builds (profiles/r02_gemm_variants10*.log); not in the shipped library
-    if (EPI == EPI_PLAIN16 && BM == 256 && p.dbg >= 16) {
-        switch (p.dbg - 16) {
+    if (EPI == EPI_PLAIN16 && BM == 256 && REID_DBG(p) >= 16) {
+        switch (REID_DBG(p) - 16) {
             case 1: mainloop_pp<BM, 256, 1>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
             case 2: mainloop_pp<BM, 256, 2>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
             case 3: mainloop_pp<BM, 256, 3>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
@@ -439,10 +441,10 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
         if (acc[0][0][0] != 1234.5f) return;
     }
 #endif
-    if (p.dbg != 4)
+    if (REID_DBG(p) != 4)
         mainloop_pp<BM, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
     GEMM_TRACE(1);
-    if (p.dbg == 1) return;
+    if (REID_DBG(p) == 1) return;
     if constexpr (EPI == EPI_MULAUX) {
         // The saved-derivative tile (256 rows x 512 B) comes in through LDS, which the K loop has just left: 128 LDS-DMA instructions
         // of two 512-byte row segments each, instead of 128 register loads of sixteen 64-byte row segments -- the register-direct form
@@ -483,11 +485,7 @@ extern "C" void reid_debug_gemm_trace(void* buf) { g_gemm_trace = (unsigned long
 template <int EPI, int BM>
 int launch_pp_e(GemmParams& p, hipStream_t s) {
     using C = PPCfg<BM, 256>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_pp_kernel<EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    REID_MAX_LDS((mer_gemm_pp_kernel<EPI, BM>), C::LDS_BYTES);
     hipLaunchKernelGGL((mer_gemm_pp_kernel<EPI, BM>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_mer_gemm");
     return REID_OK;
@@ -528,11 +526,7 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
 template <int BM, int BN, int WM, int WN, int EPI>
 int launch_e(GemmParams& p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_kernel<BM, BN, WM, WN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    REID_MAX_LDS((mer_gemm_kernel<BM, BN, WM, WN, EPI>), C::LDS_BYTES);
     hipLaunchKernelGGL((mer_gemm_kernel<BM, BN, WM, WN, EPI>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_mer_gemm");
     return REID_OK;
@@ -558,12 +552,7 @@ int launch(GemmParams& p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mer_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            C::LDS_BYTES);
-        attr_set = true;
-    }
+    REID_MAX_LDS((mer_gemm_kernel<BM, BN, WM, WN>), C::LDS_BYTES);
     const int grid = p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL((mer_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_mer_gemm");

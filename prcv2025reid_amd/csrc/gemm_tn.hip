@@ -167,11 +167,7 @@ int launch_tn(TnParams& p, hipStream_t s) {
     if (slabs > max_slabs) slabs = max_slabs;
     p.slab_rows = (((p.M + slabs - 1) / slabs) + 63) / 64 * 64;
     slabs = (p.M + p.slab_rows - 1) / p.slab_rows;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BP, BQ, WP, WQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    REID_MAX_LDS((gemm_tn_kernel<BP, BQ, WP, WQ>), LDS);
     hipLaunchKernelGGL((gemm_tn_kernel<BP, BQ, WP, WQ>), dim3(tiles * slabs), dim3(256), LDS, s, p);
     REID_CHECK_LAUNCH("reid_gemm_tn");
     return REID_OK;

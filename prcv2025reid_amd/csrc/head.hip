@@ -20,6 +20,7 @@ __global__ __launch_bounds__(SG_WAVES * 64) void sgemm_kernel(const float* __res
                                                               float* __restrict__ C, int M, int N, int K, long sam, long sak,
                                                               long sbk, long sbn, int ldc, float alpha, float beta,
                                                               const float* __restrict__ bias, int act) {
+    REID_T16_ENTER();
     __shared__ __attribute__((aligned(16))) float lds[2 * SG_WAVES * 16 * SG_PITCH];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(SG_WAVES * 64) void sgemm_kernel(const float* __res
 // ------------------------------------------------------------------------------------------ BN-neck
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ldx, int rows, int D, int rows_per_block,
                                                        float* __restrict__ sum, float* __restrict__ sqsum) {
+    REID_T16_ENTER();
     // block = 64 columns x 4 row lanes; grid = (D/64, row splits)
     __shared__ float s1[4][64], s2[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sqsum, float count, int training,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean,
                                    float* __restrict__ invstd, int D, float eps, float momentum) {
+    REID_T16_ENTER();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= D) return;
     float mu, var;
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(256) void bnneck_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ invstd, float* __restrict__ y,
                                                          bf16_t* __restrict__ yb, int ldy, float* __restrict__ rnorm, int rows,
                                                          int D, float scale) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256) void bnneck_bwd1_kernel(const float* __restric
                                                           const float* __restrict__ rnorm, float* __restrict__ dz,
                                                           float* __restrict__ sum_dz, float* __restrict__ sum_dz_xhat, int rows,
                                                           int D, float scale) {
+    REID_T16_ENTER();
     __shared__ float r1[4][MAXV * 256], r2[4][MAXV * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + w;
@@ -248,6 +253,7 @@ __global__ void bnneck_bwd2_kernel(const float* __restrict__ dz, const float* __
                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_dz,
                                    const float* __restrict__ sum_dz_xhat, float count, int training, float* __restrict__ dx, int lddx,
                                    int rows, int D) {
+    REID_T16_ENTER();
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * D) return;
     const int r = i / D, c = i % D;
@@ -273,6 +279,7 @@ __device__ __forceinline__ void row_softmax_stats(const float* __restrict__ z, i
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
                                                      const uint8_t* __restrict__ valid, int rows, int C, float eps,
                                                      float* __restrict__ row_loss, float* __restrict__ loss_sum) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
                                                      const uint8_t* __restrict__ valid, int rows, int C, float eps,
                                                      const float* __restrict__ grad_scale, float* __restrict__ dl, int lddl) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                          float* __restrict__ dx, int lddx, int rows, int D, float eps,
                                                          int accumulate) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------ small fp32 helpers of the head
 // (SDM module models/model.py:57-77 and FeatureFusion :113-183 work on [B,512] / [B,5,512] tensors: latency bound)
 __global__ void eltwise_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n, float alpha) {
+    REID_T16_ENTER();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = x[i];
         float r;
@@ -377,6 +387,7 @@ __global__ void eltwise_kernel(int op, const float* __restrict__ x, const float*
 __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __restrict__ qkv, int ld, const uint8_t* __restrict__ key_mask,
                                                              const float* __restrict__ drop, float* __restrict__ out, int ldo,
                                                              float* __restrict__ probs, int n_seq, int S, int heads) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_seq * heads) return;
@@ -416,6 +427,7 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ probs,
                                                              const float* __restrict__ drop, const float* __restrict__ dout, int ldo,
                                                              float* __restrict__ dqkv, int lddq, int n_seq, int S, int heads) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_seq * heads) return;
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const float* __rest
 // order.  M is 5 (fusion slots) or B*M (the global mean of the valid rows for all-masked samples, model.py:141-149: M = 320).
 __global__ __launch_bounds__(256) void masked_mean_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
                                                           int B, int M, int D, int bwd) {
+    REID_T16_ENTER();
     __shared__ float pc[4][64], ps[4][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, ml = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -510,8 +523,8 @@ extern "C" int reid_sgemm(const float* A, const float* B, float* C, int32_t M, i
 extern "C" int reid_bnneck_stats(const float* x, int32_t ldx, int32_t rows, int32_t D, float* sum, float* sqsum, void* stream) {
     REID_CHECK_ARG(x && sum && sqsum && rows > 0 && D > 0, "reid_bnneck_stats: bad args");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(sum, 0, D * sizeof(float), s);
-    (void)hipMemsetAsync(sqsum, 0, D * sizeof(float), s);
+    REID_CHECK_HIP(hipMemsetAsync(sum, 0, D * sizeof(float), s), "hipMemsetAsync");
+    REID_CHECK_HIP(hipMemsetAsync(sqsum, 0, D * sizeof(float), s), "hipMemsetAsync");
     int splits = (rows + 63) / 64; if (splits > 64) splits = 64;
     const int rpb = (rows + splits - 1) / splits;
     hipLaunchKernelGGL(bn_stats_kernel, dim3((D + 63) / 64, splits), dim3(256), 0, s, x, ldx, rows, D, rpb, sum, sqsum);
@@ -542,8 +555,8 @@ extern "C" int reid_bnneck_bwd_p1(const float* dy, int32_t lddy, const float* x,
     REID_CHECK_ARG(dy && x && gamma && beta && mean && invstd && rnorm && dz && sum_dz && sum_dz_xhat, "reid_bnneck_bwd_p1: null pointer");
     REID_CHECK_ARG(rows > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "reid_bnneck_bwd_p1: shape");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(sum_dz, 0, D * sizeof(float), s);
-    (void)hipMemsetAsync(sum_dz_xhat, 0, D * sizeof(float), s);
+    REID_CHECK_HIP(hipMemsetAsync(sum_dz, 0, D * sizeof(float), s), "hipMemsetAsync");
+    REID_CHECK_HIP(hipMemsetAsync(sum_dz_xhat, 0, D * sizeof(float), s), "hipMemsetAsync");
     hipLaunchKernelGGL(bnneck_bwd1_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dy, lddy, x, ldx, gamma, beta, mean, invstd, rnorm, dz,
                        sum_dz, sum_dz_xhat, rows, D, scale);
     REID_CHECK_LAUNCH("reid_bnneck_bwd_p1");

@@ -192,11 +192,7 @@ extern "C" int reid_rank_metrics(const float* scores, int64_t ld, const int32_t*
     while (cap < max_pos && cap < MAXP_LIMIT) cap <<= 1;
     MetricParams p{scores, (long long)ld, g_pid, g_img, q_pid, q_slot, q_excl, csr_off, csr_idx, ap, rank1, npos, nq, Ng, cap};
     const int lds = 12 * cap + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)rank_metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * MAXP_LIMIT + 16);
-        attr_set = true;
-    }
+    REID_MAX_LDS((rank_metrics_kernel), 12 * MAXP_LIMIT + 16);
     hipLaunchKernelGGL(rank_metrics_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, p);
     REID_CHECK_LAUNCH("reid_rank_metrics");
     return REID_OK;

@@ -126,12 +126,12 @@ __global__ __launch_bounds__(WM* WN * 64) void score_kernel(const TopkParams p) 
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + mrow;
-            th[i] = p.dbg == 2 ? INFINITY : p.thr[m < p.Nq ? m : 0];
+            th[i] = REID_DBG(p) == 2 ? INFINITY : p.thr[m < p.Nq ? m : 0];
         }
     }
     // no low-rank pair: K2 = 0 (non-null dummies keep the staging code free of constant-null pointers)
     mainloop<BM, BN, WM, WN>(p.Q, p.D, p.G, p.D, p.Q, p.D, p.G, p.D, p.Nq, p.g_end, p.D, 0, m0, n0, smem, acc);
-    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+    if (REID_DBG(p) == 1 && acc[0][0][0] != 12345.678f) return;
     if (!DENSE) {
         __syncthreads();                                    // every wave is done reading the operand buffers: reuse them
         filter_epilogue<C::TM, C::TN>(p, acc, th, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, (int*)(smem + wave * 1024));
@@ -409,11 +409,7 @@ namespace {
 template <int BM, int BN, int WM, int WN>
 int launch_filter(TopkParams p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
+    REID_MAX_LDS((score_kernel<BM, BN, WM, WN, false>), C::LDS_BYTES);
     p.tiles_m = (p.Nq + BM - 1) / BM;
     p.tiles_n = (p.Ng + BN - 1) / BN;
     hipLaunchKernelGGL((score_kernel<BM, BN, WM, WN, false>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
@@ -439,9 +435,8 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     float* dense = cscore + (size_t)Nq * cap;
     constexpr int BM = 128, BN = 128;
     using C = Cfg<BM, BN, 2, 2>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)score_kernel<BM, BN, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr_set = true; }
+    REID_MAX_LDS((score_kernel<BM, BN, 2, 2, true>), C::LDS_BYTES);
+    REID_MAX_LDS((score_kernel<BM, BN, 2, 2, false>), C::LDS_BYTES);
     TopkParams p{};
     p.Q = (const bf16_t*)Q_bf16; p.G = (const bf16_t*)G_bf16; p.Nq = Nq; p.Ng = Ng; p.D = D;
     p.exq = exclude_q; p.exg = exclude_g; p.cap = cap;
@@ -452,14 +447,13 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     p.tiles_n = (ns + BN - 1) / BN;
     hipLaunchKernelGGL((score_kernel<BM, BN, 2, 2, true>), dim3(p.tiles_m * p.tiles_n), dim3(C::NT), C::LDS_BYTES, s, p);
     REID_CHECK_LAUNCH("reid_cosine_topk(sample)");
-    static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)kth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SAMPLE * 4); attr2 = true; }   // 128 KiB: 4 waves x 8192 floats
+    REID_MAX_LDS((kth_kernel), 4 * SAMPLE * 4);   // 128 KiB: 4 waves x 8192 floats
     if (k <= 32) hipLaunchKernelGGL(kth_fast_kernel<2>, dim3((Nq + 3) / 4), dim3(256), 0, s, dense, ns, ns, k, thr, Nq);
     else if (k <= 128) hipLaunchKernelGGL(kth_fast_kernel<4>, dim3((Nq + 3) / 4), dim3(256), 0, s, dense, ns, ns, k, thr, Nq);
     else hipLaunchKernelGGL(kth_kernel, dim3((Nq + 3) / 4), dim3(256), 4 * ns * sizeof(float), s, dense, ns, ns, k, thr, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(kth)");
     // phase B: filter the whole gallery
-    (void)hipMemsetAsync(cnt, 0, (size_t)Nq * sizeof(int32_t), s);
+    REID_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)Nq * sizeof(int32_t), s), "hipMemsetAsync");
     p.g_begin = 0; p.g_end = Ng; p.thr = thr; p.dense = nullptr;
     p.cand_idx = cidx; p.cand_score = cscore; p.cand_cnt = cnt;
     {
@@ -480,8 +474,7 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     }
     // phase C
     const size_t lds = (size_t)cap * 8 + (size_t)D * 4;
-    static bool attr3 = false;
-    if (!attr3) { (void)hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 1024 * 4); attr3 = true; }
+    REID_MAX_LDS((select_kernel), 8192 * 8 + 1024 * 4);
     hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt, cap, k, out_idx, out_score, Nq);
     REID_CHECK_LAUNCH("reid_cosine_topk(select)");
     return REID_OK;
@@ -799,12 +792,8 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
     if (groups > need) groups = need;
     float* ps = (float*)ws;
     int32_t* pi = (int32_t*)(ps + (size_t)SQ * groups * k);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)stream_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LIST_BUDGET * 8);
-        (void)hipFuncSetAttribute((const void*)stream_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr = true;
-    }
+    REID_MAX_LDS((stream_merge_kernel), STREAM_LIST_BUDGET * 8);
+    REID_MAX_LDS((stream_merge_lds_kernel), 160 * 1024 - 64);
     for (int q0 = 0; q0 < Nq; q0 += SQ) {
         const int nq = Nq - q0 < SQ ? Nq - q0 : SQ;
         const float* Q = Qf + (size_t)q0 * D;

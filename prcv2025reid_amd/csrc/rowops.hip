@@ -23,6 +23,7 @@ static const char* const g_knob_names[] = {
     "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "STREAM_GROUPS", "SDM_IMPL"};
 static_assert(sizeof(g_knob_names) / sizeof(g_knob_names[0]) == KNOB_COUNT, "one name per reid_knob_id");
 static int g_knobs[KNOB_COUNT];
+static bool knob_is_debug(int i) { return i == KNOB_GEMM_DBG || i == KNOB_ATTN_DBG || i == KNOB_TOPK_DBG; }
 static int* knob_table() {
     static const bool init = [] {
         for (int i = 0; i < KNOB_COUNT; ++i) {
@@ -30,6 +31,7 @@ static int* knob_table() {
             snprintf(name, sizeof(name), "REID_%s", g_knob_names[i]);
             const char* e = getenv(name);
             g_knobs[i] = e ? atoi(e) : -1;          // -1 = "not set": every reader has its own default
+            if (knob_is_debug(i)) g_knobs[i] = -1;  // wrong-result modes: experiment builds only, and only through reid_set_knob()
         }
         return true;
     }();
@@ -40,7 +42,15 @@ int reid_knob(int id) { return knob_table()[id]; }
 extern "C" int reid_set_knob(const char* name, int value) {
     int* t = knob_table();
     for (int i = 0; i < KNOB_COUNT; ++i)
-        if (strcmp(name, g_knob_names[i]) == 0) { t[i] = value; return REID_OK; }
+        if (strcmp(name, g_knob_names[i]) == 0) {
+#ifndef REID_EXPERIMENTS
+            if (knob_is_debug(i) && value > 0) {
+                reid_set_error("reid_set_knob: %s is a wrong-result timing mode, available only in -DREID_EXPERIMENTS builds", name);
+                return REID_ERR_ARG;
+            }
+#endif
+            t[i] = value; return REID_OK;
+        }
     reid_set_error("reid_set_knob: unknown knob %s", name);
     return REID_ERR_ARG;
 }
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      bf16_t* __restrict__ yb, float* __restrict__ yf, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int cols, float eps) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      bf16_t* __restrict__ dxb, int lddx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows, int cols,
                                                      const float* __restrict__ bscale, int rows_per_img) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int nv = cols >> 2;
     constexpr bool affine = AFFINE;                       // (a separate instantiation: the accumulators cost the default path 5 % of its bandwidth)
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 // one thread = 8 consecutive pixels of one patch row -> one 16-byte bf16 store
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n_img, int H,
                                                      int W, int P, int cin) {
+    REID_T16_ENTER();
     const int gw = W / P, gh = H / P;
     const int kc = cin * P * P;                    // columns of the patch matrix
     const int chunks_per_row = kc / 8;
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 
 __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos0, float* __restrict__ x, int ldx,
                                 int n_img, int tokens, int cols) {
+    REID_T16_ENTER();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nv = cols >> 2;
     if (i >= n_img * nv) return;
@@ -254,6 +268,7 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
 }
 
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+    REID_T16_ENTER();
     const long n8 = n >> 3;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const f32x4 a = *(const f32x4*)(s + i * 8), b = *(const f32x4*)(s + i * 8 + 4);
@@ -262,11 +277,13 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __rest
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) d[n8 * 8 + threadIdx.x] = f32_to_bf16(s[n8 * 8 + threadIdx.x]);
 }
 __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long n) {
+    REID_T16_ENTER();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = bf16_to_f32(s[i]);
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const int32_t* __restrict__ index, float* __restrict__ dst,
                                    int ldd, int rows, int cols) {
+    REID_T16_ENTER();
     const int nv = cols >> 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * nv) return;
@@ -276,6 +293,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const
 
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, bf16_t* __restrict__ yb,
                                                      int ldy, int rows, int D, float eps, float scale) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -362,6 +380,7 @@ namespace {
 // out[index[r], :] += src[r, :]  (adjoint of the row gather; one wave per source row, fp32 atomics)
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int lds_, const int32_t* __restrict__ index,
                                                                float* __restrict__ out, int ldo, int rows, int cols, int out_rows) {
+    REID_T16_ENTER();
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -412,6 +431,7 @@ namespace {
 // x[b*T + t, :] = tok[ids[b, t], :] + pos[t, :]   (HF CLIPTextEmbeddings, clip_backbone.py:307): one 16-byte piece per thread
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ pos, const int64_t* __restrict__ ids,
                                                           float* __restrict__ out, int rows, int T, int D, int vocab) {
+    REID_T16_ENTER();
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int per = D >> 2;
     if (t >= (long)rows * per) return;
@@ -444,6 +464,7 @@ extern "C" int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_b
 // when dstT_off >= 0, dstT[dstT_off + c*rows + r] = bf16(src[src_off + r*cols + c]) (transposed copy).
 namespace {
 __global__ void pack_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, const int64_t* __restrict__ table, int n) {
+    REID_T16_ENTER();
     const int e = blockIdx.y;
     if (e >= n) return;
     const int64_t* t = table + (size_t)e * 5;

@@ -443,6 +443,13 @@ WsLayout ws_layout(int P, int N, int M, int D) {
 extern "C" int reid_l2norm_rows(const float* x, int32_t ldx, float* y, void* y_bf16, int32_t ldy, int32_t rows, int32_t cols, float eps,
                                 float scale, void* stream);
 
+// shape / size rules shared by the forward and the backward entry points (32-bit element offsets inside the kernels)
+static int sdm_check_shape(const char* who, int32_t P, int32_t N, int32_t Mg, int32_t D) {
+    REID_CHECK_ARG(P > 0 && N > 0 && Mg > 0 && D % 32 == 0 && D >= 32 && D <= 1024, "%s: shape P=%d N=%d Mg=%d D=%d (D %% 32, 32..1024)", who, P, N, Mg, D);
+    REID_CHECK_ARG((int64_t)P * N * D * 4 < (1ll << 32) && (int64_t)Mg * D * 4 < (1ll << 32), "%s: operands beyond 4 GiB", who);
+    return REID_OK;
+}
+
 // workspace (floats): q^ [P N D] | g^ [M D] | rstat [2 P N] | cstat [2 P M] | acc [4 P] | row / column loss terms [P N + P M] |
 //                     max( per-tile partials 4 (tiles_n P N + P tiles_m M),  gradient accumulators (P N + M) D )
 extern "C" int64_t reid_sdm_ws_floats(int32_t P, int32_t N, int32_t Mg, int32_t D) { return ws_layout(P, N, Mg, D).total; }
@@ -451,8 +458,7 @@ extern "C" int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t
                             const uint8_t* q_valid, const uint8_t* g_valid, int32_t P, int32_t N, int32_t Mg, int32_t D, float tau,
                             float* ws, float* result, void* stream) {
     REID_CHECK_ARG(q && g && q_label && g_label && ws && result, "reid_sdm_fwd: null pointer");
-    REID_CHECK_ARG(P > 0 && N > 0 && Mg > 0 && D % 32 == 0 && D >= 32 && D <= 1024, "reid_sdm_fwd: shape P=%d N=%d Mg=%d D=%d (D %% 32)", P, N, Mg, D);
-    REID_CHECK_ARG((int64_t)P * N * D * 4 < (1ll << 32) && (int64_t)Mg * D * 4 < (1ll << 32), "reid_sdm_fwd: operands beyond 4 GiB");
+    if (int rc = sdm_check_shape("reid_sdm_fwd", P, N, Mg, D)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const WsLayout w = ws_layout(P, N, Mg, D);
     int rc;
@@ -467,8 +473,7 @@ extern "C" int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t
     if (w.ts == 64) {
         hipLaunchKernelGGL(sdm_fwd_tile_kernel<64>, dim3(grid), dim3(256), Geo<64>::LDS_FWD, s, p);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)sdm_fwd_tile_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_FWD); attr = true; }
+        REID_MAX_LDS((sdm_fwd_tile_kernel<128>), Geo<128>::LDS_FWD);
         hipLaunchKernelGGL(sdm_fwd_tile_kernel<128>, dim3(grid), dim3(256), Geo<128>::LDS_FWD, s, p);
     }
     REID_CHECK_LAUNCH("reid_sdm_fwd(tiles)");
@@ -485,8 +490,8 @@ extern "C" int reid_sdm_fwd(const float* q, int32_t ldq, const float* g, int32_t
 extern "C" int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t ldg, const int64_t* q_label, const int64_t* g_label,
                             const uint8_t* q_valid, const uint8_t* g_valid, int32_t P, int32_t N, int32_t Mg, int32_t D, float tau,
                             float* ws, const float* gscale, float* dq, int32_t lddq, float* dg, int32_t lddg, void* stream) {
-    REID_CHECK_ARG(q && g && ws && gscale && dq && dg, "reid_sdm_bwd: null pointer");
-    REID_CHECK_ARG(P > 0 && N > 0 && Mg > 0 && D % 32 == 0 && D >= 32 && D <= 1024, "reid_sdm_bwd: shape");
+    REID_CHECK_ARG(q && g && q_label && g_label && ws && gscale && dq && dg, "reid_sdm_bwd: null pointer");
+    if (int rc = sdm_check_shape("reid_sdm_bwd", P, N, Mg, D)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const WsLayout w = ws_layout(P, N, Mg, D);
     SdmParams p{};
@@ -495,15 +500,13 @@ extern "C" int reid_sdm_bwd(const float* q, int32_t ldq, const float* g, int32_t
     p.inv_tau = 1.0f / fminf(fmaxf(tau, 0.15f), 0.5f);
     p.rstat = ws + w.rstat; p.cstat = ws + w.cstat; p.acc = ws + w.acc; p.gscale = gscale;
     p.dqn = ws + w.dqn; p.dgn = ws + w.dgn;
-    (void)hipMemsetAsync(ws + w.dqn, 0, ((size_t)P * N * D + (size_t)Mg * D) * sizeof(float), s);
+    REID_CHECK_HIP(hipMemsetAsync(ws + w.dqn, 0, ((size_t)P * N * D + (size_t)Mg * D) * sizeof(float), s), "reid_sdm_bwd: clearing the gradient accumulators");
     const int grid = P * w.tiles_m * w.tiles_n;
     if (w.ts == 64) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)sdm_bwd_tile_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::LDS_BWD); attr = true; }
+        REID_MAX_LDS((sdm_bwd_tile_kernel<64>), Geo<64>::LDS_BWD);
         hipLaunchKernelGGL(sdm_bwd_tile_kernel<64>, dim3(grid), dim3(256), Geo<64>::LDS_BWD, s, p);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)sdm_bwd_tile_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<128>::LDS_BWD); attr = true; }
+        REID_MAX_LDS((sdm_bwd_tile_kernel<128>), Geo<128>::LDS_BWD);
         hipLaunchKernelGGL(sdm_bwd_tile_kernel<128>, dim3(grid), dim3(256), Geo<128>::LDS_BWD, s, p);
     }
     REID_CHECK_LAUNCH("reid_sdm_bwd(tiles)");

@@ -402,16 +402,20 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
 
         Which rows of which modality go through the encoder sizes the packed batch, so it has to be known on the HOST.  Masks
         given as host tensors (what the reference's collate produces) cost nothing.  Device-resident masks (train.py:742 moves
-        the whole batch) are looked up by tensor identity + version first -- a batch object reused across steps, or a replayed
-        graph, never copies -- and otherwise read back with ONE stacked device->host copy for all modalities (the reference
-        itself synchronises five times here: ``mask.sum() > 0`` per modality, model.py:367)."""
+        the whole batch) are read back with ONE stacked device->host copy for all modalities (the reference itself synchronises
+        five times here: ``mask.sum() > 0`` per modality, model.py:367); with ``trust_mask_identity`` (opt-in, see below) they
+        are first looked up by tensor identity + version."""
         dev = torch.device(self.device)
         names = [m for m in (images or {}) if m in self.vision_modalities] + ['text']
         given = {m: (None if modality_masks is None else modality_masks.get(m)) for m in names}
         ident = (B, tuple((m, None if t is None else ((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) if torch.is_tensor(t)
                                                      else id(t))) for m, t in given.items()))
         on_dev = [m for m, t in given.items() if torch.is_tensor(t) and t.is_cuda]
-        if on_dev:
+        # The identity cache is OPT-IN (``model.trust_mask_identity = True``): (data_ptr, _version, shape) does not change when a
+        # mask buffer is rewritten behind autograd's back (a custom kernel, a graph replay filling a static buffer,
+        # ``mask.data.copy_()``), and a stale plan would silently route the wrong rows through the encoders.  Callers that own
+        # their mask tensors and modify them only through version-counted in-place ops may switch it on to skip the read-back.
+        if on_dev and getattr(self, 'trust_mask_identity', False):
             hit = self._plan_ids.get(ident)
             if hit is not None and all(given[m] is hit[1][m] for m in on_dev):       # same tensor objects, unmodified
                 return hit[0]
@@ -440,7 +444,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             if len(self._plans) > 32:
                 self._plans.clear()
             self._plans[key] = plan
-        if on_dev:
+        if on_dev and getattr(self, 'trust_mask_identity', False):
             if len(self._plan_ids) > 8:
                 self._plan_ids.clear()
             self._plan_ids[ident] = (plan, {m: given[m] for m in on_dev})               # keeps the tensors alive: ids stay unique

@@ -616,3 +616,39 @@ def test_attention_query_tile_limit(ops):
     ops.attn_bwd(qkv, o_full, do, lse_full, dq_full, delta, n_seq, S, heads)
     ops.attn_bwd(qkv, o_lim, do, lse_lim, dq_lim, delta2, n_seq, S, heads, q_tiles=1)
     assert torch.equal(dq_lim, dq_full)
+
+
+def test_f16_conversion_saturates_finite_overflow():
+    """f16 flavor: a finite value beyond IEEE half's range is stored as +-65504 by every kernel (MODE.FP16_OVFL, common.h
+    REID_T16_ENTER), infinities and NaNs pass through -- activations far beyond 65 504 give finite operands for the next GEMM
+    instead of infinities.  (bf16 has fp32's exponent range: nothing to saturate.)"""
+    from prcv2025reid_amd import ops as o, _lib
+    _lib.set_flavor('f16')
+    try:
+        src = torch.tensor([1.0, 65504.0, 65520.0, 7.0e4, 1.0e6, -1.0e6, 3.0e38, float('inf'), float('-inf'), float('nan'), -2.5, 1e-9],
+                           device='cuda')
+        dst = torch.empty(src.shape, device='cuda', dtype=torch.float16)
+        o.cast_f32_bf16(src, dst)
+        d = dst.float().cpu()
+        assert d[:7].tolist() == [1.0, 65504.0, 65504.0, 65504.0, 65504.0, -65504.0, 65504.0], d
+        assert math.isinf(float(d[7])) and float(d[7]) > 0 and math.isinf(float(d[8])) and float(d[8]) < 0 and math.isnan(float(d[9]))
+        assert float(d[10]) == -2.5
+        # GEMM epilogues (both tiles), LayerNorm output and the GELU epilogue with |values| >> 65504: finite everywhere
+        for M, N, K in ((256, 256, 128), (4096, 1536, 128)):
+            A = torch.full((M, K), 300.0, device='cuda', dtype=torch.float16)
+            A[1::2] = -300.0
+            B = torch.full((N, K), 300.0, device='cuda', dtype=torch.float16)
+            C = torch.empty(M, N, device='cuda', dtype=torch.float16)
+            G = torch.empty(M, N, device='cuda', dtype=torch.float16)
+            o.gemm(A, B, C)                                   # 128 * 9e4 = 1.15e7
+            assert torch.isfinite(C).all()
+            assert float(C[0, 0]) == 65504.0 and float(C[1, 0]) == -65504.0
+            o.gemm(A, B, G, act='gelu', C2=C)                 # gelu(1.15e7) = 1.15e7 -> 65504; gelu(-1.15e7) = -0.0
+            assert torch.isfinite(G).all() and float(G[0, 0]) == 65504.0 and float(G[1, 0]) == 0.0
+        x = torch.randn(64, 768, device='cuda') * 1e6
+        y = torch.empty(64, 768, device='cuda', dtype=torch.float16)
+        gamma = torch.full((768,), 5.0e4, device='cuda'); beta = torch.zeros(768, device='cuda')
+        o.layernorm_fwd(x, gamma, beta, y_bf16=y)             # normalised values up to ~4 * 5e4 = 2e5
+        assert torch.isfinite(y).all() and float(y.abs().max()) == 65504.0
+    finally:
+        _lib.set_flavor('bf16')

@@ -142,3 +142,23 @@ def _shard_worker(rank, world, port):
 def test_sharded_gallery_gloo():
     port = 29641
     mp.spawn(_shard_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_bench_spawn_relays_a_dead_rank_and_exits_nonzero():
+    """``bench.py --gpus 2`` (no WORLD_SIZE) on a machine whose ranks cannot start (no GPU here): the parent must notice the first dead
+    rank, stop the other, relay the ranks' stderr and exit non-zero promptly -- not sit in communicate() on rank 0."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('needs a machine without a GPU: the ranks must fail')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--spawn-timeout', '120'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'rank' in r.stderr and 'stderr (tail)' in r.stderr
+    assert time.time() - t0 < 120

@@ -120,3 +120,22 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
     for r in range(world):
         assert torch.load(os.path.join(str(tmp_path), f's{r}.pt'))['spread'] == 0.0
     print(f'  DP(2 ranks) loss {outs[0]["loss"]:.6f} vs single process {ref_loss:.6f}')
+
+
+def test_bench_gpus2_spawn_and_relay_gloo():
+    """``bench.py --gpus 2`` with no WORLD_SIZE: the CPU-only parent spawns the ranks, watches all of them and relays rank 0's line
+    (gloo rehearsal: both ranks on the one GPU of the test box; RCCL needs one GPU per rank).  Checks the keys the driver's scaling
+    run relies on."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--P', '2', '--K', '2', '--steps', '2',
+           '--warmup', '1', '--no-cpu-baseline', '--no-retrieval', '--no-parity', '--no-second-flavor', '--no-kernel-events',
+           '--spawn-timeout', '900']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1000, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 8 and line['scaling'] == 'weak'
+    assert line['params_spread_over_ranks'] == 0.0 and line['loss_spread_over_ranks'] <= 1e-5
+    assert line['n1_same_workload']['value'] > 0 and line['scaling_vs_n1_same_workload'] > 0
+    assert line['rccl_world'] == 0 and line['backend'] == 'gloo'        # (a rehearsal says so; nccl runs report rccl_world = N)
