@@ -80,6 +80,7 @@ int reid_set_knob(const char* name, int value);
  *   token rows behind the CLS slot, models/clip_backbone.py:269-270), else row m.
  * Requirements: K % 64 == 0 or K % 32 == 0, K2 % 32 == 0, N % 4 == 0, 16-byte aligned rows.
  * ------------------------------------------------------------------------------------------ */
+#define REID_GEMM_MAX_GROUPS 8
 typedef struct {
     const void* A; const void* B; const void* A2; const void* B2;
     const float* bias;
@@ -96,6 +97,15 @@ typedef struct {
     float alpha;
     const float* row_scale;   /* optional f32 [rows / rows_per_img]: out = R + row_scale[row / rows_per_img] * (A.B^T + bias)  (DropPath,
                                  clip_backbone.py:137-141: per-sample branch scale 0 or 1/keep); NULL = 1 */
+    /* Row groups (MERLinear routing of mer_lora.py:80-99 for a batch packed modality by modality): with n_row_groups > 0 the rows
+     * [row_group_end[g-1], row_group_end[g]) (row_group_end[-1] = 0; the last end must equal M) use weight matrix number
+     * row_group_b[g] of a stack: B + row_group_b[g] * b_group_stride (16-bit elements).  The stack holds the MERGED weights
+     * W + (alpha/r) B_mu A_mu of each modality (reid_merge_lora), so shared_linear(x) + lora_B(lora_A(x)) * s is ONE GEMM without
+     * a K extension.  Row tiles never straddle two groups. */
+    int32_t n_row_groups;
+    int32_t row_group_end[REID_GEMM_MAX_GROUPS];
+    int32_t row_group_b[REID_GEMM_MAX_GROUPS];
+    int64_t b_group_stride;
 } reid_gemm_args;
 int reid_mer_gemm(const reid_gemm_args* host_args, void* stream);
 
@@ -168,6 +178,14 @@ int reid_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
  * table[e] = {src_off, rows, cols, dst_off, dstT_off} (int64, element offsets; a negative dst offset skips that copy).
  * dst gets the same-layout bf16 copy at dst_off and the TRANSPOSED bf16 copy at dstT_off.  One launch per step. */
 int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table, int32_t n_entries, void* stream);
+/* Merged MER-LoRA weights (mer_lora.py:80-99): for every table entry e and modality mu < nmod
+ *     W_eff[e][mu] = W_e + scaling * Bcat_e[:, mu r : (mu+1) r] . Acat_e[g Rp + mu r : g Rp + (mu+1) r, :]      (16-bit, rounded once)
+ * and its transpose -- the operands of reid_mer_gemm's row-group form.  table[e] = {W pointer (f32 [N, K] contiguous), arena
+ * offset of Acat [G*Rp, K], arena offset of Bcat [N, Rp], destination offset of W_eff [nmod][N][K], destination offset of
+ * W_eff^T [nmod][K][N] (negative: skip), N, K, G} (int64; offsets in elements; N, K, N/G multiples of 64; G = projections fused
+ * along N, each with its own adapter rows g Rp ...).  max_tiles >= (N/64)(K/64) of every entry.  One launch per optimizer step. */
+int reid_merge_lora_table(const int64_t* table, int32_t n_entries, int32_t max_tiles, const float* arena, void* weff,
+                          int32_t Rp, int32_t r, int32_t nmod, float scaling, void* stream);
 /* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */
 int reid_gather_rows_f32(const float* src, int32_t lds, const int32_t* index, float* dst, int32_t ldd,
                          int32_t rows, int32_t cols, void* stream);

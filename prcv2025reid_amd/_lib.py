@@ -41,7 +41,7 @@ EXPORTS = [
     'reid_eltwise_f32', 'reid_small_attn_fwd', 'reid_small_attn_bwd', 'reid_masked_mean',
     'reid_opt_entry_bytes', 'reid_opt_ws_floats', 'reid_opt_state_floats', 'reid_opt_sumsq', 'reid_opt_clip', 'reid_opt_adamw',
     'reid_rank_metrics', 'reid_scatter_add_rows_f32', 'reid_embed_tokens',
-    'reid_topk_stream_ok', 'reid_topk_stream_ws_bytes', 'reid_cosine_topk_stream',
+    'reid_topk_stream_ok', 'reid_topk_stream_ws_bytes', 'reid_cosine_topk_stream', 'reid_merge_lora_table',
 ]
 
 
@@ -57,7 +57,9 @@ class GemmArgs(C.Structure):
                 ('r_period', C.c_int32),
                 ('mask_r', C.c_int32), ('mask_period', C.c_int32), ('rows_per_img', C.c_int32),
                 ('c_group', C.c_int32), ('c_group_stride', C.c_int32), ('c_row_off', C.c_int32),
-                ('alpha', C.c_float), ('row_scale', C.c_void_p)]
+                ('alpha', C.c_float), ('row_scale', C.c_void_p),
+                ('n_row_groups', C.c_int32), ('row_group_end', C.c_int32 * 8), ('row_group_b', C.c_int32 * 8),
+                ('b_group_stride', C.c_int64)]
 
 
 _libs = {}

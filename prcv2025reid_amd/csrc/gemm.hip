@@ -37,6 +37,12 @@ struct GemmParams {
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
     int epi;      // EPI_*: which epilogue the kernel instance was built with (host side choice)
+    // Row groups (n_groups > 0): activation rows [grp_row0[g], grp_row_end[g]) multiply weight matrix number grp_b[g] of a stack of
+    // [N, K] matrices b_group_stride elements apart (the per-modality merged weights W + s B_mu A_mu: images are packed modality by
+    // modality).  Row tiles never straddle groups: group g owns global row-tile indices [grp_tile0[g], grp_tile0[g + 1]).
+    int n_groups;
+    int grp_row0[REID_GEMM_MAX_GROUPS], grp_row_end[REID_GEMM_MAX_GROUPS], grp_tile0[REID_GEMM_MAX_GROUPS], grp_b[REID_GEMM_MAX_GROUPS];
+    long b_group_stride;
     unsigned long long* trace;   // REID_GEMM_TRACE builds: 8 words per workgroup (timestamps at start / loop end / epilogue issued / acknowledged, HW ids)
 };
 
@@ -51,6 +57,23 @@ struct GemmParams {
 enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4, EPI_GELU2D = 5, EPI_MULAUX = 6 };
 
 using namespace gemmcore;
+
+// first row, row limit and weight matrix of global row tile `tm` (tile height BM)
+__device__ __forceinline__ void tile_rows(const GemmParams& p, int tm, int BM, int& m0, int& m_end, const bf16_t*& B) {
+    B = p.B;
+    if (p.n_groups > 0) {
+        int g = 0;
+#pragma unroll
+        for (int i = 1; i < REID_GEMM_MAX_GROUPS; ++i)
+            if (i < p.n_groups && tm >= p.grp_tile0[i]) g = i;
+        m0 = p.grp_row0[g] + (tm - p.grp_tile0[g]) * BM;
+        m_end = p.grp_row_end[g];
+        B += (size_t)p.grp_b[g] * p.b_group_stride;
+    } else {
+        m0 = tm * BM;
+        m_end = p.M;
+    }
+}
 
 // Epilogue of one wave's [TM*16 x TN*16] sub-tile whose first element is C[m_base][n_base], straight from the
 // accumulators (no LDS round trip, no waits between pieces).
@@ -126,14 +149,14 @@ __device__ __forceinline__ void init_acc(const GemmParams& p, f32x4 (&acc)[TN][T
 }
 
 template <int TM, int TN, int MODE>
-__device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+__device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane, int m_end) {
     constexpr int CW = MODE == 1 ? 8 : 4;
     constexpr int NP = TN * 4 / CW;                     // pieces per lane per 16-row group
     constexpr int NQ = TM * NP;                         // pieces per lane
     constexpr int RD = (32 / CW) < NQ ? (32 / CW) : NQ; // residual / aux pieces in flight per lane (32 VGPRs of fp32)
     static_assert(MODE != 1 || TN % 2 == 0, "8-wide pieces pair two MFMA sub-tiles");
     const int frow = lane & 15, fq = lane >> 4;
-    const int mlast = p.M - 1;
+    const int mlast = m_end - 1;
     const bool has_r = p.R != nullptr;
     const bool has_aux = p.act >= REID_ACT_DGELU_ERF && p.act <= REID_ACT_MUL_AUX;
     Piece<CW> rv[RD];
@@ -158,7 +181,7 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
         const int i = q / NP, pc = q % NP, slot = q % RD;
         const int m = m_base + i * 16 + frow;
         const int n = col_of(pc);
-        const bool ok = m < p.M && n < p.N;
+        const bool ok = m < m_end && n < p.N;
         size_t crow = (size_t)m;
         if (p.c_group > 0) crow = (size_t)(m / p.c_group) * p.c_group_stride + (m % p.c_group) + p.c_row_off;
         float v[CW];
@@ -226,7 +249,7 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
 // 16-byte chunks of row r stored at position chunk ^ (r & 15) (stage_aux_tile below); lrow0 / lchunk0 = this wave's first row /
 // first chunk in that image.
 template <int TM, int TN, int EPI>
-__device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane,
+__device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane, int m_end,
                                                 const char* aux_lds = nullptr, int lrow0 = 0, int lchunk0 = 0) {
     const int frow = lane & 15, fq = lane >> 4;
     // Operand loads (residual, saved derivative) are ALL issued before the first use, half a tile at a time: one exposed memory
@@ -244,7 +267,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
             for (int ii = 0; ii < HG; ++ii) {
                 if (half * HG + ii >= TM) break;
                 const int m = m_base + 16 * (half * HG + ii) + frow;
-                const int mc = m < p.M ? m : p.M - 1;
+                const int mc = m < m_end ? m : m_end - 1;
                 const uint32_t ro = ((uint32_t)mc * (uint32_t)p.ldr + col) * 4u;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) r[ii][j] = *(const f32x4*)(R + ro + 64u * j);
@@ -255,8 +278,8 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
                 const int i = half * HG + ii;
                 if (i >= TM) break;
                 const int m = m_base + 16 * i + frow;
-                const bool ok = m < p.M;
-                const uint32_t co = ((uint32_t)(ok ? m : p.M - 1) * (uint32_t)p.ldc + col) * 4u;
+                const bool ok = m < m_end;
+                const uint32_t co = ((uint32_t)(ok ? m : m_end - 1) * (uint32_t)p.ldc + col) * 4u;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const f32x4 v = acc[j][i] * rs[ii] + r[ii][j];
@@ -281,7 +304,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = m_base + 16 * i + frow;
-                const int mc = m < p.M ? m : p.M - 1;
+                const int mc = m < m_end ? m : m_end - 1;
                 const uint32_t ao = ((uint32_t)mc * (uint32_t)p.ldaux + col) * 2u;
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc) av[i][pc] = *(const bf16x8*)((const char*)p.aux + ao + 64u * pc);
@@ -290,8 +313,8 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m_base + 16 * i + frow;
-            const bool ok = m < p.M;
-            const int mc = ok ? m : p.M - 1;
+            const bool ok = m < m_end;
+            const int mc = ok ? m : m_end - 1;
             const uint32_t co = ((uint32_t)mc * (uint32_t)p.ldc + col) * 2u;
             const uint32_t c2o = (EPI == EPI_GELU2 || EPI == EPI_GELU2D) ? ((uint32_t)mc * (uint32_t)p.ldc2 + col) * 2u : 0u;
 #pragma unroll
@@ -329,6 +352,17 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
     }
 }
 
+// host side: number of row tiles of height bm (per row group when groups are on) and, with `fill`, the tile index ranges of the groups
+static int row_tiles(GemmParams& p, int bm, bool fill) {
+    if (p.n_groups <= 0) return (p.M + bm - 1) / bm;
+    int t = 0;
+    for (int g = 0; g < p.n_groups; ++g) {
+        if (fill) p.grp_tile0[g] = t;
+        t += (p.grp_row_end[g] - p.grp_row0[g] + bm - 1) / bm;
+    }
+    return t;
+}
+
 // host side: which lean epilogue (if any) covers this launch
 static int pick_epilogue(const GemmParams& p, int BN) {
     if (p.alpha != 1.f || p.mask_r > 0 || p.c_group > 0 || p.r_period > 0 || p.N % BN != 0) return EPI_GENERIC;
@@ -354,10 +388,10 @@ __host__ __device__ inline bool epilogue_wide16(const GemmParams& p) {
 }
 
 template <int TM, int TN>
-__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
-    if (p.c_dtype == REID_F32) store_tile_m<TM, TN, 0>(p, acc, m_base, n_base, lane);
-    else if (p.perm_b) store_tile_m<TM, TN, 1>(p, acc, m_base, n_base, lane);
-    else store_tile_m<TM, TN, 2>(p, acc, m_base, n_base, lane);
+__device__ __forceinline__ void store_tile(const GemmParams& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane, int m_end) {
+    if (p.c_dtype == REID_F32) store_tile_m<TM, TN, 0>(p, acc, m_base, n_base, lane, m_end);
+    else if (p.perm_b) store_tile_m<TM, TN, 1>(p, acc, m_base, n_base, lane, m_end);
+    else store_tile_m<TM, TN, 2>(p, acc, m_base, n_base, lane, m_end);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI = EPI_GENERIC>
@@ -374,7 +408,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0, m_end;
+    const bf16_t* Bw;
+    tile_rows(p, tm, BM, m0, m_end, Bw);
+    const int n0 = tn * BN;
     const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
 
@@ -383,14 +420,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
     else if constexpr (EPI == EPI_RES32) init_acc_m<C::TM, C::TN, 0>(p, acc, n0 + wn * (BN / WN), lane);
     else init_acc_m<C::TM, C::TN, 1>(p, acc, n0 + wn * (BN / WN), lane);
     if (REID_DBG(p) != 4)
-        mainloop<BM, BN, WM, WN>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc,
+        mainloop<BM, BN, WM, WN>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc,
                                  p.perm_b != 0);
 
     // ------------------------------------------------------------------ epilogue (registers -> global, no LDS)
     constexpr int WTM = BM / WM, WTN = BN / WN;
     if (REID_DBG(p) == 1) return;
-    if constexpr (EPI == EPI_GENERIC) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else store_tile_fast<C::TM, C::TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    if constexpr (EPI == EPI_GENERIC) store_tile<C::TM, C::TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, m_end);
+    else store_tile_fast<C::TM, C::TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, m_end);
 }
 
 // 256 x 256 tile with the wave-row ping-pong K loop of gemm_core.h (mainloop_pp); epilogue = the same register-direct code
@@ -420,7 +457,10 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
     const int lin = xcd_linear_block(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
-    const int m0 = tm * BM, n0 = tn * 256;
+    int m0, m_end;
+    const bf16_t* Bw;
+    tile_rows(p, tm, BM, m0, m_end, Bw);
+    const int n0 = tn * 256;
     const int g = (p.k2_group_n > 0) ? (n0 / p.k2_group_n) : 0;
     const bf16_t* A2 = p.A2 ? p.A2 + (size_t)g * p.K2 : nullptr;
     f32x4 acc[4][TM];
@@ -430,19 +470,19 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
 #ifdef REID_GEMM_ABLATIONS                                  // K-loop anatomy builds (profiles/r02_gemm_variants10*.log); not in the shipped library
     if (EPI == EPI_PLAIN16 && BM == 256 && REID_DBG(p) >= 16) {
         switch (REID_DBG(p) - 16) {
-            case 1: mainloop_pp<BM, 256, 1>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 2: mainloop_pp<BM, 256, 2>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 3: mainloop_pp<BM, 256, 3>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 4: mainloop_pp<BM, 256, 4>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 6: mainloop_pp<BM, 256, 6>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
-            case 11: mainloop_pp<BM, 256, 11>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 1: mainloop_pp<BM, 256, 1>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 2: mainloop_pp<BM, 256, 2>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 3: mainloop_pp<BM, 256, 3>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 4: mainloop_pp<BM, 256, 4>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 6: mainloop_pp<BM, 256, 6>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
+            case 11: mainloop_pp<BM, 256, 11>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0); break;
             default: break;
         }
         if (acc[0][0][0] != 1234.5f) return;
     }
 #endif
     if (REID_DBG(p) != 4)
-        mainloop_pp<BM, 256>(p.A, p.lda, p.B, p.ldb, A2, p.lda2, p.B2, p.ldb2, p.M, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
+        mainloop_pp<BM, 256>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
     GEMM_TRACE(1);
     if (REID_DBG(p) == 1) return;
     if constexpr (EPI == EPI_MULAUX) {
@@ -455,13 +495,13 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
             const int rp = q * 8 + wave;                     // row pair
             const int row = 2 * rp + (lane >> 5);
             const int c = lane & 31;                         // destination chunk position; it holds source chunk c ^ (row & 15)
-            const int gm = m0 + row < p.M ? m0 + row : p.M - 1;
+            const int gm = m0 + row < m_end ? m0 + row : m_end - 1;
             const char* src = (const char*)p.aux + ((size_t)gm * p.ldaux + n0) * 2 + ((c ^ (row & 15)) << 4);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + rp * 1024), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, smem, wm * RW, wn * 8);
+        store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, m_end, smem, wm * RW, wn * 8);
         GEMM_TRACE(2);
 #ifdef REID_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -469,8 +509,8 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
 #endif
         return;
     }
-    if constexpr (EPI == EPI_GENERIC) store_tile<TM, 4>(p, acc, m0 + wm * RW, n0 + wn * 64, lane);
-    else store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane);
+    if constexpr (EPI == EPI_GENERIC) store_tile<TM, 4>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, m_end);
+    else store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, m_end);
     GEMM_TRACE(2);
 #ifdef REID_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -498,13 +538,14 @@ static int pick_pp_bm(const GemmParams& p, int tile_knob) {
     if (tile_knob == 14) return 224;
     const long cus = reid_num_cus();
     const long tn = p.N / 256;
-    const long t256 = ((p.M + 255) / 256) * tn, t224 = ((p.M + 223) / 224) * tn;
+    GemmParams q = p;
+    const long t256 = (long)row_tiles(q, 256, false) * tn, t224 = (long)row_tiles(q, 224, false) * tn;
     return (t224 + cus - 1) / cus <= (t256 + cus - 1) / cus ? 224 : 256;
 }
 int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 256);
     const int bm = p.epi == EPI_GENERIC ? 256 : pick_pp_bm(p, tile_knob);     // (the generic epilogue is only built for the 256-row tile)
-    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_m = row_tiles(p, bm, true);
     p.tiles_n = (p.N + 255) / 256;
     p.stagger = reid_knob(KNOB_GEMM_STAGGER) > 0 ? reid_knob(KNOB_GEMM_STAGGER) : 0;
 #ifdef REID_GEMM_TRACE
@@ -533,7 +574,7 @@ int launch_e(GemmParams& p, hipStream_t s) {
 }
 // the default 128 x 128 tile with the lean epilogue that covers the launch (GENERIC otherwise)
 int launch_main(GemmParams& p, hipStream_t s) {
-    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_m = row_tiles(p, 128, true);
     p.tiles_n = (p.N + 127) / 128;
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 128);
     switch (p.epi) {
@@ -550,7 +591,7 @@ int launch_main(GemmParams& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 int launch(GemmParams& p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
-    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_m = row_tiles(p, BM, true);
     p.tiles_n = (p.N + BN - 1) / BN;
     REID_MAX_LDS((mer_gemm_kernel<BM, BN, WM, WN>), C::LDS_BYTES);
     const int grid = p.tiles_m * p.tiles_n;
@@ -589,12 +630,35 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
                    "reid_mer_gemm: modality mask needs img_mod, rows_per_img, mask_period");
     REID_CHECK_ARG(a->c_group == 0 || a->c_group_stride >= a->c_group, "reid_mer_gemm: c_group_stride");
     REID_CHECK_ARG(!a->row_scale || a->rows_per_img > 0, "reid_mer_gemm: row_scale needs rows_per_img");
+    REID_CHECK_ARG(a->n_row_groups >= 0 && a->n_row_groups <= REID_GEMM_MAX_GROUPS, "reid_mer_gemm: n_row_groups=%d (max %d)", a->n_row_groups, REID_GEMM_MAX_GROUPS);
+    if (a->n_row_groups > 0) {
+        int prev = 0;
+        for (int g = 0; g < a->n_row_groups; ++g) {
+            REID_CHECK_ARG(a->row_group_end[g] > prev, "reid_mer_gemm: row_group_end must be strictly increasing (empty groups are left out by the caller)");
+            REID_CHECK_ARG(a->row_group_b[g] >= 0, "reid_mer_gemm: row_group_b[%d] < 0", g);
+            REID_CHECK_ARG((int64_t)(a->row_group_b[g] + 1) * a->b_group_stride * 2 < (1ll << 40), "reid_mer_gemm: weight stack too large");
+            prev = a->row_group_end[g];
+        }
+        REID_CHECK_ARG(prev == a->M, "reid_mer_gemm: the row groups must cover exactly M=%d rows (last end %d)", a->M, prev);
+        REID_CHECK_ARG(a->b_group_stride >= (int64_t)a->N * a->ldb, "reid_mer_gemm: b_group_stride smaller than one [N, ldb] matrix");
+        REID_CHECK_ARG(a->c_group == 0 && a->r_period == 0, "reid_mer_gemm: row groups do not combine with c_group / r_period");
+    }
     GemmParams p;
     p.stagger = 0;
     p.trace = nullptr;
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.A2 = (const bf16_t*)a->A2; p.B2 = (const bf16_t*)a->B2;
     p.bias = a->bias; p.R = a->R; p.aux = (const bf16_t*)a->aux; p.C = a->C; p.C2 = a->C2; p.img_mod = a->img_mod; p.row_scale = a->row_scale;
     p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->A2 ? a->K2 : 0;
+    p.n_groups = a->n_row_groups;
+    p.b_group_stride = a->b_group_stride;
+    for (int g = 0; g < REID_GEMM_MAX_GROUPS; ++g) {
+        p.grp_row0[g] = p.grp_row_end[g] = p.grp_tile0[g] = p.grp_b[g] = 0;
+        if (g < a->n_row_groups) {
+            p.grp_row0[g] = g == 0 ? 0 : a->row_group_end[g - 1];
+            p.grp_row_end[g] = a->row_group_end[g];
+            p.grp_b[g] = a->row_group_b[g];
+        }
+    }
     p.lda = a->lda; p.ldb = a->ldb; p.lda2 = a->lda2; p.ldb2 = a->ldb2; p.ldr = a->ldr; p.ldaux = a->ldaux;
     p.ldc = a->ldc; p.ldc2 = a->ldc2; p.k2_group_n = a->k2_group_n;
     p.act = a->act; p.c_dtype = a->c_dtype; p.c2_dtype = a->c2_dtype; p.r_dtype = a->r_dtype;
@@ -617,7 +681,12 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     //  loads (16 rows x 64 bytes per instruction) cost the vector-memory path more than the LDS round trip saves; stand-alone
     //  the tiled form already streams at 4.9-5.4 TB/s -- the 31 us seen in the train step is interference from the dA/dB
     //  reductions on the side stream, not this kernel.)
-    if (a->N <= 32) return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
+    if (a->N <= 32) {
+        const int sk = reid_knob(KNOB_SKINNY_TILE);
+        if (sk == 1) return launch<256, 32, 4, 1>(p, s);
+        if (sk == 2) return launch<128, 32, 4, 1>(p, s);
+        return a->M >= 65536 ? launch<256, 32, 4, 1>(p, s) : launch<64, 32, 4, 1>(p, s);
+    }
     if (a->N <= 64) return a->M >= 65536 ? launch<256, 64, 4, 1>(p, s) : launch<64, 64, 4, 1>(p, s);
     if (a->N <= 96) return launch<128, 32, 4, 1>(p, s);
     // experiment knobs (cached table, common.h; a benchmark A/Bs tiles inside one process through reid_set_knob)
@@ -642,7 +711,7 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         // and 2.8 us between tiles -- hipcc waits vmcnt(0) for the bias loads of the accumulator init and for the queue index, which
         // drains the prefetch at every tile start, and the loop carries ~40 spilled registers across tile boundaries.)
         const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
-        const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
+        const long tiles256 = (long)row_tiles(p, 256, false) * (p.N / 256);
         const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();
         if (pp_ok && (tile == 12 || tile == 14 || (tile == 0 && pp_shape && reid_knob(KNOB_GEMM_EPI) != 0 && pick_epilogue(p, 256) != EPI_GENERIC)))
             return launch_pp(p, s, tile);

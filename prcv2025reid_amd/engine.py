@@ -5,9 +5,13 @@ Vision (reference: CLIPUnifiedEncoder.encode_vision clip_backbone.py:254-286, ME
 patch_embeds.py:45-76).  MI355X-first differences from the reference's execution (same arithmetic):
 
 * ALL vision modalities of a batch go through the 12 blocks in ONE pass: valid images are packed
-  [n_img, 197, 768]; the per-modality LoRA adapters are applied inside the shared GEMM as a K
-  extension: T = mask_modality(h . Acat^T) * (alpha/r) is a skinny GEMM whose epilogue zeroes the
-  columns of other modalities, then  out = h.W^T + T.Bcat^T + b  is ONE MFMA GEMM (K = 768 + Rp).
+  [n_img, 197, 768] modality by modality.  The per-modality LoRA adapters live INSIDE the weights:
+  once per optimizer step ``reid_merge_lora_table`` forms W_eff[mu] = W + (alpha/r) B_mu A_mu for every
+  linear and modality (16-bit, both orientations: 1.4 GB of the 288 GB), and every MERLinear is ONE plain
+  MFMA GEMM whose row tiles pick the matrix of their modality (row groups of reid_mer_gemm) -- no
+  rank-r side computation on the critical path, no K extension.  What the adapter GRADIENTS need
+  (T = x A^T in the forward, U = dY B in the backward, dA = U^T x, dB = dY^T T) runs on a second HIP
+  stream from tensors the main stream produces anyway.
   4x fewer, 4x larger launches than the reference's one-encoder-pass-per-modality loop.
 * q|k|v are one [768 -> 2304] GEMM; LayerNorm-1 is computed once (the reference evaluates it 3x).
 * residual stream fp32, MFMA operands bf16, fp32 accumulate; GELU / residual / bias fused in epilogues.
@@ -46,7 +50,7 @@ class LoraLayout:
         self.L = arch['vision_layers']
         d, ff, Rp = self.d, self.ff, self.Rp
         self.dims = {'qkv': (3, d, 3 * d), 'out': (1, d, d), 'fc1': (1, d, ff), 'fc2': (1, ff, d)}   # G, K(in), N(out)
-        off = 0; poff = 0
+        off = 0; poff = 0; woff = 0
         self.ent = {}
         for l in range(self.L):
             for nm in LIN:
@@ -59,9 +63,13 @@ class LoraLayout:
                 e['pAT'] = poff; poff += G * Rp * K
                 e['pB'] = poff; poff += N * Rp
                 e['pBT'] = poff; poff += N * Rp
+                # merged weights W + (alpha/r) B_mu A_mu per modality: [nmod, N, K] and the transposes [nmod, K, N]
+                e['wE'] = woff; woff += self.nmod * N * K
+                e['wET'] = woff; woff += self.nmod * N * K
                 self.ent[(l, nm)] = e
         self.size = off
         self.pack_size = poff
+        self.weff_size = woff
 
     def table(self) -> torch.Tensor:
         rows = []
@@ -88,6 +96,13 @@ class LoraLayout:
     def view_B(self, arena, l, nm):
         o, shp = self.ent[(l, nm)]['B']
         return arena[o:o + shp[0] * shp[1]].view(shp)
+
+    def weff(self, arena, l, nm, transposed=False):
+        """Merged weight stack of one linear: [nmod, N, K] (forward operand) or [nmod, K, N] (dX operand)."""
+        e = self.ent[(l, nm)]
+        N, K = e['N'], e['K']
+        o = e['wET'] if transposed else e['wE']
+        return arena[o:o + self.nmod * N * K].view((self.nmod, K, N) if transposed else (self.nmod, N, K))
 
     def pk(self, pack, l, nm, which):
         e = self.ent[(l, nm)]
@@ -121,6 +136,8 @@ class Engine:
         self._dense_ver = None
         self._lora_ver = None
         self._lora_pack = None
+        self._weff = None
+        self._merge_table = None
         self._table = None
         self._side = None
         self._tside = None
@@ -131,9 +148,9 @@ class Engine:
         self.text_backward_ready = True
         self._text_packed = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
-        self.tn_defer = os.environ.get('REID_TN_DEFER', '0') == '1'    # experiment: MLP / out-proj dA, dB reductions held back until the attention backward
         self.cls_prune = os.environ.get('REID_CLS_PRUNE', '1') != '0'
         self.W = {}
+        self.W32 = {}
 
     def _const(self, key, make):
         """Small index tensors that depend only on the batch layout: built once per layout and kept on the device (a
@@ -152,8 +169,17 @@ class Engine:
         return self._tside
 
     def _side_stream(self):
+        """Stream of the adapter-gradient kernels: LOWEST priority, so its workgroups are dispatched only where the main stream has
+        none pending (the partly filled last round of a GEMM, gaps between kernels) instead of taking compute units from it."""
         if self._side is None:
-            self._side = torch.cuda.Stream(self.dev)
+            prio = os.environ.get('REID_SIDE_PRIORITY')
+            if prio is None:
+                try:
+                    least, _greatest = torch.cuda.Stream.priority_range()
+                except Exception:
+                    least = 0
+                prio = least
+            self._side = torch.cuda.Stream(self.dev, priority=int(prio))
         return self._side
 
     # ------------------------------------------------------------------------------- packing
@@ -168,12 +194,11 @@ class Engine:
         ce = 'clip_encoder.'
         for l in range(a['vision_layers']):
             lp = f'{ce}vision_layers.{l}.'
-            wq = torch.cat([P[lp + f'attn.{n}_proj.shared_linear.weight'].detach() for n in 'qkv'], 0)
-            W[('v', l, 'qkv')] = self._bf(wq); W[('v', l, 'qkvT')] = self._bft(wq)
+            # fp32 masters of the four linears: the merge kernel reads them (the 16-bit operands are the merged stacks, pack_lora)
+            self.W32[(l, 'qkv')] = torch.cat([P[lp + f'attn.{n}_proj.shared_linear.weight'].detach() for n in 'qkv'], 0).contiguous()
             W[('v', l, 'bqkv')] = torch.cat([P[lp + f'attn.{n}_proj.shared_linear.bias'].detach() for n in 'qkv'], 0).contiguous()
             for nm, ref in (('out', 'attn.out_proj'), ('fc1', 'mlp.fc1'), ('fc2', 'mlp.fc2')):
-                w = P[lp + ref + '.shared_linear.weight']
-                W[('v', l, nm)] = self._bf(w); W[('v', l, nm + 'T')] = self._bft(w)
+                self.W32[(l, nm)] = P[lp + ref + '.shared_linear.weight'].detach().contiguous()
         for m in self.lay.vmods:
             w = P[f'{ce}patch_embeds.{m}.proj.weight']
             W[('pe', m)] = self._bf(w.reshape(w.shape[0], -1))
@@ -197,20 +222,60 @@ class Engine:
         if self.text_trains():
             W['tprojT'] = self._bft(P[ce + 'text_proj.weight'])
         self.W = W
+        self._merge_table = None                              # the fp32 master pointers may have moved
 
     def pack_lora(self):
+        """16-bit copies of the adapters (A, A^T, B, B^T: operands of the gradient-side kernels) and the merged weight stacks
+        W_eff[mu] = W + (alpha/r) B_mu A_mu (operands of every MERLinear GEMM): two launches per optimizer step."""
+        lay = self.lay
         if self._lora_pack is None:
-            self._lora_pack = torch.empty(self.lay.pack_size, dtype=_lib.t16(), device=self.dev)
-            self._table = self.lay.table().to(self.dev)
-        ops.pack_bf16_table(self.lora_arena.detach(), self._lora_pack, self._table, self._table.shape[0])
+            self._lora_pack = torch.empty(lay.pack_size, dtype=_lib.t16(), device=self.dev)
+            self._table = lay.table().to(self.dev)
+        if self._weff is None:
+            self._weff = torch.empty(lay.weff_size, dtype=_lib.t16(), device=self.dev)
+        if self._merge_table is None:
+            rows = []
+            for (l, nm), e in lay.ent.items():
+                w = self.W32[(l, nm)]
+                assert w.shape == (e['N'], e['K']) and w.is_contiguous() and w.dtype == torch.float32
+                rows.append([w.data_ptr(), e['A'][0], e['B'][0], e['wE'], e['wET'], e['N'], e['K'], e['G']])
+            self._merge_table = torch.tensor(rows, dtype=torch.int64).to(self.dev)
+            self._merge_tiles = max((e['N'] // 64) * (e['K'] // 64) for e in lay.ent.values())
+        arena = self.lora_arena.detach()
+        self.wait_packed()                                   # (a previous pack nobody consumed must not overlap writers of the arena)
+        # Both launches go to a stream of their own, forked from the caller's: the merge (~1.7 GB of traffic) then runs beside the
+        # patch embedding and the text tower instead of in front of them; the first vision block waits for it (wait_packed).
+        main = torch.cuda.current_stream(self.dev)
+        ps = self._pack_stream()
+        ev = torch.cuda.Event(); ev.record(main); ps.wait_event(ev)
+        with torch.cuda.stream(ps):
+            ops.pack_bf16_table(arena, self._lora_pack, self._table, self._table.shape[0])
+            ops.merge_lora_table(self._merge_table, self._merge_table.shape[0], self._merge_tiles, arena, self._weff, lay.Rp, lay.r,
+                                 lay.nmod, self.scaling)
+            self._pack_event = torch.cuda.Event(); self._pack_event.record(ps)
+
+    def wait_packed(self):
+        """Make the current stream (and the adapter-gradient side stream) wait for the last pack_lora."""
+        ev = getattr(self, '_pack_event', None)
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            if self._side is not None:
+                self._side.wait_event(ev)
+            self._pack_event = None
+
+    def _pack_stream(self):
+        if getattr(self, '_pstream', None) is None:
+            self._pstream = torch.cuda.Stream(self.dev)
+        return self._pstream
 
     def refresh(self):
         dv = sum(p._version for k, p in self.P.items() if k.startswith('clip_encoder.') and p is not self.lora_arena)
         tt = self.text_trains()
-        if dv != self._dense_ver or tt != self._text_packed:
+        dense_changed = dv != self._dense_ver or tt != self._text_packed
+        if dense_changed:
             self.pack_dense(); self._dense_ver = dv; self._text_packed = tt
         lv = self.lora_arena._version
-        if lv != self._lora_ver:
+        if lv != self._lora_ver or dense_changed:
             self.pack_lora(); self._lora_ver = lv
 
     # ------------------------------------------------------------------------------- vision forward
@@ -255,10 +320,22 @@ class Engine:
         ops.cls_rows(P[ce + 'cls_token'].view(-1), pos[0], x, n_img, S)
         mk = dict(img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=S, alpha=self.scaling)
         pk = lambda l, nm, w: lay.pk(self._lora_pack, l, nm, w)
+        we = lambda l, nm: lay.weff(self._weff, l, nm)
+        # row groups of the merged-weight GEMMs: images are packed modality by modality
+        counts = [g[1].shape[0] for g in groups if g[1].shape[0] > 0]
+        mus = [g[0] for g in groups if g[1].shape[0] > 0]
+        ends = [0]
+        for c in counts:
+            ends.append(ends[-1] + c)
+        rg_full = ([e * S for e in ends[1:]], mus)
+        rg_cls = (ends[1:], mus)
         saved = []
         buf = {}
         idx = self._const(('cls_idx', n_img, S), lambda: torch.arange(n_img, dtype=torch.int32) * S)
         idxl = self._const(('cls_idx64', n_img, S), lambda: torch.arange(n_img, dtype=torch.int64) * S)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream() if (save and self.overlap_tn) else None
+        self.wait_packed()                                   # merged weights / adapter packs of this step (pack_lora's stream)
 
         def new(name, shape, kw):
             if save:
@@ -268,14 +345,24 @@ class Engine:
                 t = buf[name] = torch.empty(shape, **kw)
             return t
 
+        def lora_down(calls):
+            """T = mask_modality(x . Acat^T) * (alpha/r) for the block's four linears: needed only by the backward pass (dB = dY^T T),
+            so it runs beside the main stream's GEMMs (same inputs, fresh in L2 / Infinity Cache) instead of in front of them."""
+            if side is None:
+                for xin_, A_, T_, kw in calls:
+                    ops.gemm(xin_, A_, T_, **kw)
+                return
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for xin_, A_, T_, kw in calls:
+                    ops.gemm(xin_, A_, T_, **kw)
+
         for l in range(a['vision_layers']):
             lp = f'{ce}vision_layers.{l}.'
             h = new('h', (M, d), b16); mean1 = new('m1', (M,), f32); rstd1 = new('r1', (M,), f32)
             ops.layernorm_fwd(x, P[lp + 'ln1.weight'], P[lp + 'ln1.bias'], y_bf16=h, mean=mean1, rstd=rstd1)
-            T = new('T', (M, 3 * Rp), b16)
-            ops.gemm(h, pk(l, 'qkv', 'A'), T, **mk)
             qkv = new('qkv', (M, 3 * d), b16)
-            ops.gemm(h, W[('v', l, 'qkv')], qkv, A2=T, B2=pk(l, 'qkv', 'B'), K2=Rp, k2_group_n=d, bias=W[('v', l, 'bqkv')])
+            ops.gemm(h, we(l, 'qkv'), qkv, bias=W[('v', l, 'bqkv')], row_groups=rg_full)
             o = new('o', (M, d), b16); lse = new('lse', (n_img, heads, S), f32)
             ops.attn_fwd(qkv, o, lse, n_img, S, heads, q_tiles=1 if (self.cls_prune and l == a['vision_layers'] - 1) else 0)
             sa, sm_ = (None, None) if drop_scales is None else drop_scales[l]
@@ -284,30 +371,30 @@ class Engine:
                 # Only the class-token row of the last block's output is ever used (clip_backbone.py:281: x[:, 0]), and rows do
                 # not mix after the attention core: out-projection, LN2 and the MLP of the LAST block run on the n_img class rows
                 # instead of all n_img*197 (same function; the reference computes and discards the other 196/197).
-                Mr, rpi = n_img, 1
+                Mr, rpi, rg = n_img, 1, rg_cls
                 xin = x.index_select(0, idxl); oin = o.index_select(0, idxl)
             else:
-                Mr, rpi = M, S
+                Mr, rpi, rg = M, S, rg_full
                 xin, oin = x, o
             mkr = dict(img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=self.scaling)
-            To = new('To', (Mr, Rp), b16)
-            ops.gemm(oin, pk(l, 'out', 'A'), To, **mkr)
             xm = new('xm', (Mr, d), f32)
-            ops.gemm(oin, W[('v', l, 'out')], xm, A2=To, B2=pk(l, 'out', 'B'), K2=Rp,
-                     bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=xin, row_scale=sa, rows_per_img=rpi)
+            ops.gemm(oin, we(l, 'out'), xm, bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=xin, row_scale=sa, rows_per_img=rpi,
+                     row_groups=rg)
             h2 = new('h2', (Mr, d), b16); mean2 = new('m2', (Mr,), f32); rstd2 = new('r2', (Mr,), f32)
             ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
-            T1 = new('T1', (Mr, Rp), b16)
-            ops.gemm(h2, pk(l, 'fc1', 'A'), T1, **mkr)
             u = new('u', (Mr, ff), b16) if save else None      # holds gelu'(pre-activation): the backward epilogue is one multiply
             g = new('g', (Mr, ff), b16)
-            ops.gemm(h2, W[('v', l, 'fc1')], g, A2=T1, B2=pk(l, 'fc1', 'B'), K2=Rp,
-                     bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu_dsave' if save else 'gelu', C2=u)
-            T2 = new('T2', (Mr, Rp), b16)
-            ops.gemm(g, pk(l, 'fc2', 'A'), T2, **mkr)
+            ops.gemm(h2, we(l, 'fc1'), g, bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu_dsave' if save else 'gelu', C2=u,
+                     row_groups=rg)
+            T = To = T1 = T2 = None
+            if save:
+                T = torch.empty(M, 3 * Rp, **b16); To = torch.empty(Mr, Rp, **b16)
+                T1 = torch.empty(Mr, Rp, **b16); T2 = torch.empty(Mr, Rp, **b16)
+                lora_down([(h, pk(l, 'qkv', 'A'), T, mk), (oin, pk(l, 'out', 'A'), To, mkr), (h2, pk(l, 'fc1', 'A'), T1, mkr),
+                           (g, pk(l, 'fc2', 'A'), T2, mkr)])
             xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
-            ops.gemm(g, W[('v', l, 'fc2')], xn, A2=T2, B2=pk(l, 'fc2', 'B'), K2=Rp,
-                     bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi)
+            ops.gemm(g, we(l, 'fc2'), xn, bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi,
+                     row_groups=rg)
             if save:
                 saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
                                   mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2, sa=sa, sm=sm_, cls=last, o_rows=oin))
@@ -318,7 +405,7 @@ class Engine:
         feats = torch.empty(n_img, a['fusion_dim'], **f32)
         ops.gemm(cls_h, W['vproj'], feats)
         state = dict(layers=saved, x_final=x, idx=idx, idxl=idxl, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
-                     groups=groups, cls_prune=self.cls_prune) if save else None
+                     groups=groups, cls_prune=self.cls_prune, rg_full=rg_full, rg_cls=rg_cls) if save else None
         return feats, state
 
     # ------------------------------------------------------------------------------- vision backward
@@ -390,47 +477,62 @@ class Engine:
         else:
             ops.layernorm_bwd(dcls, st['x_final'], P[ce + 'vision_ln_final.weight'], st['mf'], st['rf'], dx, dx_bf16=dxb,
                               row_index=st['idx'], bf16_row_scale=st['layers'][-1]['sm'], rows_per_img=S, dgamma=dgf, dbeta=dbf)
-        # reusable scratch (one U per linear: the side stream still reads it while the next skinny GEMM runs)
+        # Scratch.  Everything the SIDE stream reads (the dY of the four linears: dxb, du, dxmb, dqkv) exists twice, used by alternate
+        # layers: the main stream may then run a whole layer ahead of the adapter-gradient kernels without overwriting their inputs.
+        # U* (= dY . Bcat, the rank-r cotangents) are written and read on the side stream only.
         U2 = torch.empty(M, Rp, **b16); U1 = torch.empty(M, Rp, **b16); Uo = torch.empty(M, Rp, **b16)
         Uq = torch.empty(M, 3 * Rp, **b16)
-        du = torch.empty(M, ff, **b16); dh = torch.empty(M, d, **b16); do = torch.empty(M, d, **b16)
-        dqkv = torch.empty(M, 3 * d, **b16); delta = torch.empty(n_img, heads, S, **f32)
-        dxm = torch.empty(M, d, **f32); dxmb = torch.empty(M, d, **b16)
-        # The reduce-over-rows GEMMs that produce dA/dB are HBM-bound and independent of the dX chain: they go to a
-        # second HIP stream so they fill the bubbles of the MFMA-bound dX GEMMs (joined once per layer).
+        du2 = [torch.empty(M, ff, **b16) for _ in range(2)]
+        dqkv2 = [torch.empty(M, 3 * d, **b16) for _ in range(2)]
+        dxmb2 = [torch.empty(M, d, **b16) for _ in range(2)]
+        dxb2 = [dxb, torch.empty(M, d, **b16)]
+        dh = torch.empty(M, d, **b16); do = torch.empty(M, d, **b16)
+        delta = torch.empty(n_img, heads, S, **f32)
+        dxm = torch.empty(M, d, **f32)
+        weT = lambda l, nm: lay.weff(self._weff, l, nm, transposed=True)
+        rg_full, rg_cls = st['rg_full'], st['rg_cls']
         main = torch.cuda.current_stream(dev)
         side = self._side_stream() if self.overlap_tn else None
+        side_done = {}
+        L = a['vision_layers']
+        # the gradient ENTERING layer l (dx times that layer's MLP DropPath factor, 16-bit) lives in dxb2[l & 1]
+        if not prune:
+            cur_dxb = dxb2[(L - 1) & 1]
+            if cur_dxb is not dxb:
+                cur_dxb.copy_(dxb)
 
-        pending = []
-        defer = self.tn_defer and side is not None
-
-        def fork(*calls, flush=False):
+        def lora_grads(l, calls):
+            """Adapter gradients of one linear on the side stream: U = mask(dY . Bcat) * (alpha/r), dB += dY^T T, dA += U^T X.
+            ``calls`` = [(dY, BT, U, mask kwargs, [(X operand, Y operand, out), ...])]."""
             if side is None:
-                for c in calls:
-                    ops.gemm_tn(*c, beta=1.0)
-                return
-            if defer and not flush:                         # hold the MLP / out-projection reductions back until the attention backward
-                pending.extend(calls)
-                return
-            calls = tuple(pending) + calls
-            pending.clear()
-            if not calls:
+                for dY, BT, U, kw, tns in calls:
+                    ops.gemm(dY, BT, U, **kw)
+                    for xx, yy, out in tns:
+                        ops.gemm_tn(xx, yy, out, beta=1.0)
                 return
             ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
             with torch.cuda.stream(side):
-                for c in calls:
-                    ops.gemm_tn(*c, beta=1.0)
+                for dY, BT, U, kw, tns in calls:
+                    ops.gemm(dY, BT, U, **kw)
+                    for xx, yy, out in tns:
+                        ops.gemm_tn(xx, yy, out, beta=1.0)
 
-        def join():
+        def layer_done(l):
             if side is not None:
-                ev = torch.cuda.Event(); ev.record(side); main.wait_event(ev)
+                ev = torch.cuda.Event(); ev.record(side); side_done[l] = ev
 
-        for l in reversed(range(a['vision_layers'])):
+        def wait_side(l):
+            ev = side_done.pop(l, None)
+            if ev is not None:
+                main.wait_event(ev)
+
+        for l in reversed(range(L)):
             s = st['layers'][l]
             lp = f'{ce}vision_layers.{l}.'
+            b = l & 1
             c = bool(s.get('cls'))                          # this block's MLP / out-projection ran on the class rows only
             if c:
-                Mr = n_img
+                Mr, rg = n_img, rg_cls
                 mkr = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=1, alpha=self.scaling)
                 gy, gyb = dx_c, dxb_c
                 U2r = torch.empty(Mr, Rp, **b16); U1r = torch.empty(Mr, Rp, **b16); Uor = torch.empty(Mr, Rp, **b16)
@@ -438,19 +540,18 @@ class Engine:
                 dxmr = torch.empty(Mr, d, **f32); dxmbr = torch.empty(Mr, d, **b16)
                 rpi = 1
             else:
-                Mr, mkr, gy, gyb = M, mk, dx, dxb
-                U2r, U1r, Uor, dur, dhr, dor, dxmr, dxmbr, rpi = U2, U1, Uo, du, dh, do, dxm, dxmb, S
-            # ---- fc2:  x_next = xm + g W2^T + b2 + T2 B2^T
-            ops.gemm(gyb, pk(l, 'fc2', 'BT'), U2r, **mkr)
-            fork((gyb, s['T2'], gB(l, 'fc2')), (U2r, s['g'], gA(l, 'fc2')))
-            ops.gemm(gyb, W[('v', l, 'fc2T')], dur, A2=U2r, B2=pk(l, 'fc2', 'AT'), K2=Rp, act='mul_aux', aux=s['u'])
+                Mr, mkr, gy, gyb, rg = M, mk, dx, dxb2[b], rg_full
+                U2r, U1r, Uor, dur, dhr, dor, dxmr, dxmbr, rpi = U2, U1, Uo, du2[b], dh, do, dxm, dxmb2[b], S
+            dqkv = dqkv2[b]
+            # ---- fc2:  x_next = xm + g W2_eff^T + b2
+            lora_grads(l, [(gyb, pk(l, 'fc2', 'BT'), U2r, mkr, [(gyb, s['T2'], gB(l, 'fc2')), (U2r, s['g'], gA(l, 'fc2'))])])
+            ops.gemm(gyb, weT(l, 'fc2'), dur, act='mul_aux', aux=s['u'], row_groups=rg)
             if want_dense:
                 dense[lp + 'mlp.fc2.shared_linear.weight'] = wgrad(gyb, s['g'])
                 dense[lp + 'mlp.fc2.shared_linear.bias'] = colsum(gyb)
-            # ---- fc1:  u = h2 W1^T + b1 + T1 B1^T
-            ops.gemm(dur, pk(l, 'fc1', 'BT'), U1r, **mkr)
-            fork((dur, s['T1'], gB(l, 'fc1')), (U1r, s['h2'], gA(l, 'fc1')))
-            ops.gemm(dur, W[('v', l, 'fc1T')], dhr, A2=U1r, B2=pk(l, 'fc1', 'AT'), K2=Rp)
+            # ---- fc1:  u = h2 W1_eff^T + b1
+            lora_grads(l, [(dur, pk(l, 'fc1', 'BT'), U1r, mkr, [(dur, s['T1'], gB(l, 'fc1')), (U1r, s['h2'], gA(l, 'fc1'))])])
+            ops.gemm(dur, weT(l, 'fc1'), dhr, row_groups=rg)
             if want_dense:
                 dense[lp + 'mlp.fc1.shared_linear.weight'] = wgrad(dur, s['h2'])
                 dense[lp + 'mlp.fc1.shared_linear.bias'] = colsum(dur)
@@ -458,10 +559,9 @@ class Engine:
             dg2, db2 = ln_grads(lp + 'ln2')
             ops.layernorm_bwd(dhr, s['xm'], P[lp + 'ln2.weight'], s['mean2'], s['rstd2'], dxmr, dx_bf16=dxmbr, dres=gy,
                               bf16_row_scale=s['sa'], rows_per_img=rpi, dgamma=dg2, dbeta=db2)
-            # ---- out proj:  xm = x + o Wo^T + bo + To Bo^T
-            ops.gemm(dxmbr, pk(l, 'out', 'BT'), Uor, **mkr)
-            fork((dxmbr, s['To'], gB(l, 'out')), (Uor, s['o_rows'], gA(l, 'out')))
-            ops.gemm(dxmbr, W[('v', l, 'outT')], dor, A2=Uor, B2=pk(l, 'out', 'AT'), K2=Rp)
+            # ---- out proj:  xm = x + o Wo_eff^T + bo
+            lora_grads(l, [(dxmbr, pk(l, 'out', 'BT'), Uor, mkr, [(dxmbr, s['To'], gB(l, 'out')), (Uor, s['o_rows'], gA(l, 'out'))])])
+            ops.gemm(dxmbr, weT(l, 'out'), dor, row_groups=rg)
             if want_dense:
                 dense[lp + 'attn.out_proj.shared_linear.weight'] = wgrad(dxmbr, s['o_rows'])
                 dense[lp + 'attn.out_proj.shared_linear.bias'] = colsum(dxmbr)
@@ -469,32 +569,32 @@ class Engine:
                 do.zero_(); do.index_copy_(0, idxl, dor)
                 dxm.zero_(); dxm.index_copy_(0, idxl, dxmr)
             # ---- attention
-            if defer:
-                fork(flush=True)
             ops.attn_bwd(s['qkv'], s['o'], do, s['lse'], dqkv, delta, n_img, S, heads, q_tiles=1 if c else 0)
-            # ---- qkv:  qkv = h Wqkv^T + b + T Bqkv^T (one adapter set per projection)
+            # ---- qkv:  qkv = h Wqkv_eff^T + b (one adapter set per projection)
             bT = pk(l, 'qkv', 'BT')                         # [Rp, 3d]
             gBq = gB(l, 'qkv')                              # [3d, Rp]
-            for g in range(3):
-                ops.gemm(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], **mk)
-            fork(*[(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d]) for g in range(3)],
-                 (Uq, s['h'], gA(l, 'qkv')), flush=True)
+            lora_grads(l, [(dqkv[:, g * d:(g + 1) * d], bT[:, g * d:(g + 1) * d], Uq[:, g * Rp:(g + 1) * Rp], mk,
+                            [(dqkv[:, g * d:(g + 1) * d], s['T'][:, g * Rp:(g + 1) * Rp], gBq[g * d:(g + 1) * d])] +
+                            ([(Uq, s['h'], gA(l, 'qkv'))] if g == 2 else [])) for g in range(3)])
+            layer_done(l)
             if l == 0 and not want_dense:
                 # nothing below layer 0 trains under the default freeze: the gradient of the embedded sequence (dX of the
                 # q|k|v projection and the LN1 backward) would be computed only to be thrown away
-                join()
                 break
-            ops.gemm(dqkv, W[('v', l, 'qkvT')], dh, A2=Uq, B2=pk(l, 'qkv', 'AT'), K2=3 * Rp)
+            ops.gemm(dqkv, weT(l, 'qkv'), dh, row_groups=rg_full)
             if want_dense:
                 gw = wgrad(dqkv, s['h']); gb_ = colsum(dqkv)
                 for gi, nm in enumerate('qkv'):
                     dense[lp + f'attn.{nm}_proj.shared_linear.weight'] = gw[gi * d:(gi + 1) * d]
                     dense[lp + f'attn.{nm}_proj.shared_linear.bias'] = gb_[gi * d:(gi + 1) * d]
-            # ---- LN1 (rewrites dxb, and the next layer rewrites du/dxmb/dqkv/U*: the side stream must be done with them)
-            join()
+            # ---- LN1: writes the gradient entering layer l - 1 into the OTHER buffer set; its previous readers on the side stream
+            # are the adapter-gradient kernels of layer l + 1 (and this layer's successor will overwrite du / dxmb / dqkv of that set)
+            wait_side(l + 1)
             dg1, db1 = ln_grads(lp + 'ln1')
-            ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb, dres=dxm,
+            ops.layernorm_bwd(dh, s['x'], P[lp + 'ln1.weight'], s['mean1'], s['rstd1'], dx, dx_bf16=dxb2[(l - 1) & 1], dres=dxm,
                               bf16_row_scale=st['layers'][l - 1]['sm'] if l > 0 else None, rows_per_img=S, dgamma=dg1, dbeta=db1)
+        if side is not None:                                # the gradient arena is complete only when the side stream is
+            ev = torch.cuda.Event(); ev.record(side); main.wait_event(ev)
         if want_dense:
             # embedded sequence x0[img, t] = (cls | patch_t) + pos[t]: dx now holds d loss / d x0
             ones_r = torch.ones(1, n_img, **f32)

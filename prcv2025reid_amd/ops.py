@@ -31,13 +31,24 @@ def gemm_profile_end():
 
 def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None, r_period=0, aux=None,
          C2=None, act='none', img_mod=None, mask_r=0, mask_period=0, rows_per_img=0,
-         c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None, row_scale=None):
-    """C_out = epilogue(A @ B.T + A2 @ B2.T + bias); see reid_mer_gemm in include/reid_hip.h."""
+         c_group=0, c_group_stride=0, c_row_off=0, alpha=1.0, M=None, row_scale=None, row_groups=None):
+    """C_out = epilogue(A @ B.T + A2 @ B2.T + bias); see reid_mer_gemm in include/reid_hip.h.
+    ``row_groups`` = (row_ends, weight_indices): B is then a stack [n_mats, N, K]; rows [row_ends[g-1], row_ends[g]) use B[weight_indices[g]]."""
     a = GemmArgs()
     a.A, a.B, a.C = ptr(A), ptr(B), ptr(C_out)
     a.M = A.shape[0] if M is None else M
-    a.N, a.K = B.shape[0], B.shape[1]
-    a.lda, a.ldb, a.ldc = A.stride(0), B.stride(0), C_out.stride(0)
+    if row_groups is not None:
+        ends, widx = row_groups
+        a.N, a.K = B.shape[1], B.shape[2]
+        a.ldb = B.stride(1)
+        a.n_row_groups = len(ends)
+        for i, (e_, w_) in enumerate(zip(ends, widx)):
+            a.row_group_end[i] = e_; a.row_group_b[i] = w_
+        a.b_group_stride = B.stride(0)
+    else:
+        a.N, a.K = B.shape[0], B.shape[1]
+        a.ldb = B.stride(0)
+    a.lda, a.ldc = A.stride(0), C_out.stride(0)
     a.c_dtype = L.dt(C_out)
     if A2 is not None:
         a.A2, a.B2 = ptr(A2), ptr(B2)
@@ -159,6 +170,10 @@ def cast_f32_bf16(src, dst):
 def cast_bf16_f32(src, dst):
     check(lib().reid_cast_bf16_f32(ptr(src), ptr(dst), C.c_int64(src.numel()), stream_ptr()))
     return dst
+
+
+def merge_lora_table(table, n_entries, max_tiles, arena, weff, Rp, r, nmod, scaling):
+    check(lib().reid_merge_lora_table(ptr(table), n_entries, max_tiles, ptr(arena), ptr(weff), Rp, r, nmod, C.c_float(scaling), stream_ptr()))
 
 
 def to_bf16(src: torch.Tensor) -> torch.Tensor:

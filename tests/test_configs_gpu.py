@@ -10,7 +10,7 @@ The oracle's encoders need minutes of CPU at these batch sizes, so the checks ar
   * ce_valid_cnt = number of samples with at least one valid modality (model.py:540-546);
   * gradient accumulation: the gradient the optimizer sees after two micro-batches through StepDriver(accum_steps=2) equals
     (g_A + g_B) / 2 of the two micro-batches run separately (train.py:833-834,895), and the optimizer runs once;
-  * everything finite, gradients non-zero, null-token gradients only where a modality was masked somewhere.
+  * everything finite, LoRA gradients non-zero.
 The 8-GPU forms of both configs need a node (the driver's SCALE run); the arithmetic of the data-parallel path itself is
 tests/test_parallel_gpu.py.
 """
@@ -134,9 +134,8 @@ def test_config5_per_gpu_slice_full_size_accum2():
         grads.append([(p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for p in ps])
         for p in ps:
             assert p.grad is None or torch.isfinite(p.grad).all()
-        nulls = {k: p for k, p in model.named_parameters() if k.startswith('null_tokens.')}
-        for m in ('nir', 'sk', 'cp', 'text'):                # a masked modality's slot holds its null token: that token trains
-            assert float(nulls[f'null_tokens.{m}'].grad.abs().max()) > 0, m
+        # (a masked slot holds the modality's null token, but the fusion's key mask and masked mean and the SDM pairs all leave
+        #  masked rows out -- model.py:141-149,586-622 -- so null tokens receive exactly zero gradient here, as in the reference)
         for p in model.parameters():
             p.grad = None
     groups = [dict(params=[p for p in gr['params'] if p.requires_grad], lr=gr['lr'], name=gr['name']) for gr in model.get_learnable_params()]

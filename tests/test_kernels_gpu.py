@@ -652,3 +652,90 @@ def test_f16_conversion_saturates_finite_overflow():
         assert torch.isfinite(y).all() and float(y.abs().max()) == 65504.0
     finally:
         _lib.set_flavor('bf16')
+
+
+@pytest.mark.parametrize('r,G,N,K', [(8, 1, 768, 768), (4, 3, 384, 128), (16, 1, 256, 3072)])
+def test_merge_lora_table(ops, r, G, N, K):
+    """reid_merge_lora_table: W_eff[mu] = W + s B_mu A_mu per modality (mer_lora.py:80-99 with the adapter folded into the weight),
+    rounded once to 16 bits; the transposed stack is the EXACT transpose."""
+    g = torch.Generator(device='cuda').manual_seed(r + G + N)
+    nmod = 4
+    Rp = ((nmod * r + 31) // 32) * 32
+    W = torch.randn(N, K, device='cuda', generator=g) * 0.03
+    arena = torch.randn(G * Rp * K + N * Rp + 64, device='cuda', generator=g) * 0.2
+    offA, offB = 32, 32 + G * Rp * K
+    A = arena[offA:offA + G * Rp * K].view(G * Rp, K); B = arena[offB:offB + N * Rp].view(N, Rp)
+    weff = torch.zeros(2 * nmod * N * K + 128, device='cuda', dtype=T16())
+    oE, oET = 64, 64 + nmod * N * K
+    table = torch.tensor([[W.data_ptr(), offA, offB, oE, oET, N, K, G]], dtype=torch.int64, device='cuda')
+    s = 1.0 / r
+    ops.merge_lora_table(table, 1, (N // 64) * (K // 64), arena, weff, Rp, r, nmod, s)
+    E = weff[oE:oE + nmod * N * K].view(nmod, N, K); ET = weff[oET:oET + nmod * N * K].view(nmod, K, N)
+    assert torch.equal(ET, E.transpose(1, 2))
+    assert float(weff[:oE].float().abs().max()) == 0 and float(weff[oET + nmod * N * K:].float().abs().max()) == 0
+    n_g = N // G
+    for mu in range(nmod):
+        ref = W.clone()
+        for gi in range(G):
+            ref[gi * n_g:(gi + 1) * n_g] += s * (B[gi * n_g:(gi + 1) * n_g, mu * r:(mu + 1) * r].double() @
+                                                 A[gi * Rp + mu * r: gi * Rp + (mu + 1) * r].double()).float()
+        got = E[mu].float()
+        # one rounding of the fp32 sum: within half a 16-bit ulp of the reference (+ fp32 summation-order noise)
+        ulp = 2.0 ** (-8 if T16() == torch.bfloat16 else -11)
+        assert float(((got - ref).abs() / ref.abs().clamp_min(1e-3)).max()) <= ulp * 1.01 + 1e-5, mu
+
+
+@pytest.mark.parametrize('N,K,epi', [(768, 768, 'res32'), (2304, 768, 'plain16'), (3072, 768, 'gelu2d'), (768, 3072, 'res32'),
+                                     (3072, 768, 'mulaux'), (96, 768, 'generic')])
+def test_gemm_row_groups(ops, N, K, epi):
+    """Row-group form of reid_mer_gemm: rows of group g multiply weight matrix row_group_b[g] of a stack; tiles never straddle
+    groups; ragged group sizes (multiples of 197 rows), 128 x 128 tile and both ping-pong tiles, every lean epilogue + the generic one."""
+    g = torch.Generator(device='cuda').manual_seed(N + K + len(epi))
+    S = 197
+    imgs, mus = [10, 14, 9, 7], [2, 0, 3, 1]
+    M = sum(imgs) * S
+    ends, e = [], 0
+    for n in imgs:
+        e += n * S; ends.append(e)
+    A = bf(torch.randn(M, K, device='cuda', generator=g))
+    Wst = bf(torch.randn(4, N, K, device='cuda', generator=g) * 0.03)
+    bias = torch.randn(N, device='cuda', generator=g) * 0.1
+    ref = torch.empty(M, N, device='cuda')
+    lo = 0
+    for hi, mu in zip(ends, mus):
+        ref[lo:hi] = A[lo:hi].float() @ Wst[mu].float().t() + bias
+        lo = hi
+    rg = (ends, mus)
+    if epi == 'res32':
+        R = torch.randn(M, N, device='cuda', generator=g)
+        rs = (torch.rand(sum(imgs), device='cuda', generator=g) > 0.3).float() / 0.7
+        C = torch.empty(M, N, device='cuda')
+        ops.gemm(A, Wst, C, bias=bias, R=R, row_scale=rs, rows_per_img=S, row_groups=rg)
+        want = R + ref * rs.repeat_interleave(S).view(-1, 1)
+        assert rel_err(C, want) < 3e-5
+    elif epi == 'plain16' or epi == 'generic':
+        C = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(A, Wst, C, bias=bias, row_groups=rg)
+        assert rel_err(C.float(), ref) < 1e-2
+        Cf = torch.empty(M, N, device='cuda')
+        ops.gemm(A, Wst, Cf, bias=bias, row_groups=rg)
+        assert rel_err(Cf, ref) < 3e-5
+    elif epi == 'gelu2d':
+        C = torch.empty(M, N, device='cuda', dtype=T16()); C2 = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(A, Wst, C, bias=bias, act='gelu_dsave', C2=C2, row_groups=rg)
+        x = ref.double()
+        cdf = 0.5 * (1 + torch.erf(x / math.sqrt(2))); pdf = torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        assert rel_err(C.float(), (x * cdf).float()) < 1e-2
+        assert rel_err(C2.float(), (cdf + x * pdf).float()) < 1e-2
+    else:
+        aux = bf(torch.randn(M, N, device='cuda', generator=g))
+        C = torch.empty(M, N, device='cuda', dtype=T16())
+        ops.gemm(A, Wst, C, act='mul_aux', aux=aux, row_groups=rg)
+        assert rel_err(C.float(), (ref - bias) * aux.float()) < 1e-2
+    # rows of one group must not see another group's matrix: a single-group call on a slice gives the same bits
+    lo, hi, mu = ends[0], ends[1], mus[1]
+    Cs = torch.empty(hi - lo, N, device='cuda')
+    ops.gemm(A[lo:hi], Wst[mu], Cs, bias=bias)
+    Cg = torch.empty(M, N, device='cuda')
+    ops.gemm(A, Wst, Cg, bias=bias, row_groups=rg)
+    assert rel_err(Cg[lo:hi], Cs) < 1e-6

@@ -254,6 +254,7 @@ def test_everything_trains_vs_reference_fixture():
     cfg, arch, state, batch, tokens = case_inputs(meta)
     check_fingerprint(z, state)
     model = build_model(meta, state, True, 'f16')
+    model._case = dict(state=state, arch=arch, training=True, flavor='f16', meta=meta, labels=batch['person_id'])
     for k, p in model.named_parameters():
         p.requires_grad_(True)
     images = {m: t.cuda() for m, t in batch['images'].items()}
