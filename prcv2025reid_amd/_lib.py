@@ -7,6 +7,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATHS = {'bf16': os.path.join(_HERE, 'csrc', 'libreid_hip.so'), 'f16': os.path.join(_HERE, 'csrc', 'libreid_hip_f16.so')}
+if os.environ.get('REID_LIB_BF16'):                 # experiment builds (tools/): another bf16-flavor library file
+    LIB_PATHS['bf16'] = os.environ['REID_LIB_BF16']
 LIB_PATH = LIB_PATHS['bf16']
 T16_DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16}
 _flavor = os.environ.get('REID_T16', 'bf16')

@@ -242,6 +242,19 @@ __device__ __forceinline__ void store_tile_m(const GemmParams& p, f32x4 (&acc)[T
     }
 }
 
+// Output stores of the lean epilogues.  -DREID_NT_STORES: non-temporal (the tile is written once and never re-read by this kernel, so it
+// need not displace the operand panels the XCD's other workgroups are re-reading from L2).
+template <typename T>
+__device__ __forceinline__ void st_out(T* ptr, const T& v) {
+#ifdef REID_NT_STORES
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(T) == 16, "16-byte pieces");
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)ptr);
+#else
+    *ptr = v;
+#endif
+}
+
 // Lean epilogues (host side guarantees: N a multiple of the tile, every stride a multiple of 8 elements, every operand below
 // 4 GiB, alpha == 1, no mask / row remap / periodic residual).  Layout as in store_tile_m: the 16-bit kinds use the perm32
 // weight-row staging (a lane owns 8 consecutive columns per pair of MFMA sub-tiles), EPI_RES32 the natural one (4 columns).
@@ -283,7 +296,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const f32x4 v = acc[j][i] * rs[ii] + r[ii][j];
-                    if (ok) *(f32x4*)(C + co + 64u * j) = v;
+                    if (ok) st_out((f32x4*)(C + co + 64u * j), v);
                 }
             }
         }
@@ -323,7 +336,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[2 * pc + (e >> 2)][i][e & 3];
                 if constexpr (EPI == EPI_GELU2) {
-                    if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                    if (ok) st_out((uint4*)((char*)p.C2 + c2o + 64u * pc), uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         f32x2_t gg, dd;
@@ -338,7 +351,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
                         gelu_both_x2(f32x2_t{v[e], v[e + 1]}, gg, dd);
                         v[e] = gg.x; v[e + 1] = gg.y; dv[e] = dd.x; dv[e + 1] = dd.y;
                     }
-                    if (ok) *(uint4*)((char*)p.C2 + c2o + 64u * pc) = uint4{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]), pack_bf16x2(dv[4], dv[5]), pack_bf16x2(dv[6], dv[7])};
+                    if (ok) st_out((uint4*)((char*)p.C2 + c2o + 64u * pc), uint4{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]), pack_bf16x2(dv[4], dv[5]), pack_bf16x2(dv[6], dv[7])});
                 } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_f(bf16_to_f32((bf16_t)av[i][pc][e]));
@@ -346,7 +359,7 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= bf16_to_f32((bf16_t)av[i][pc][e]);
                 }
-                if (ok) *(uint4*)(C + co + 64u * pc) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                if (ok) st_out((uint4*)(C + co + 64u * pc), uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
             }
         }
     }
@@ -522,6 +535,75 @@ static unsigned long long* g_gemm_trace = nullptr;
 extern "C" void reid_debug_gemm_trace(void* buf) { g_gemm_trace = (unsigned long long*)buf; }
 #endif
 
+// PERSISTENT ping-pong kernel (gemm_core.h stream_pp): gridDim.x = number of CUs (a multiple of 8), every workgroup walks tiles
+// blockIdx.x, + gridDim.x, ... in the same XCD-aware / L2-aware order the one-tile-per-workgroup kernel is dispatched in, and
+// prefetches the next tile's first two K-tiles under the last two of the current one.  Lean register-only epilogues only.
+template <int EPI, int BM = 256>
+__global__ __launch_bounds__(512, 2) void mer_gemm_pps_kernel(const GemmParams p) {
+    REID_T16_ENTER();
+    using PC = PPCfg<BM, 256>;
+    constexpr int TM = PC::TM, RW = PC::RW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n_tiles = p.tiles_m * p.tiles_n;
+    auto tile_of = [&](int v, int& m0, int& m_end, int& n0, const bf16_t*& Bw) {
+        const int lin = xcd_linear_block(v, n_tiles);
+        int tm, tn;
+        tile_coords(lin, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
+        tile_rows(p, tm, BM, m0, m_end, Bw);
+        n0 = tn * 256;
+    };
+    auto init = [&](f32x4 (&acc)[4][TM], int n0) {
+        if constexpr (EPI == EPI_RES32) init_acc_m<TM, 4, 0>(p, acc, n0 + wn * 64, lane);
+        else init_acc_m<TM, 4, 1>(p, acc, n0 + wn * 64, lane);
+    };
+    auto epi = [&](f32x4 (&acc)[4][TM], int m0, int m_end, int n0) {
+        store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, m_end);
+    };
+#ifdef REID_GEMM_TRACE
+    // per tile: 0 tile start, 1 accumulators initialised (bias landed), 2 K loop minus its last two K-tiles done, 3 next tile's offsets set,
+    // 4 K loop done, 5 epilogue issued (thread 0 = wave row 0); 6 = the same epilogue point seen by wave row 1 (thread 256), 7 = CU id
+    auto trace = [&](int v, int slot) {
+        if (!p.trace) return;
+        if (threadIdx.x == 0) {
+            p.trace[(size_t)v * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+#ifndef REID_GEMM_TRACE_CLOCK
+            if (slot == 0) p.trace[(size_t)v * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#endif
+        }
+#ifdef REID_GEMM_TRACE_CLOCK
+        // shader clock over the K loop: slots 6 / 7 = s_memtime at trace points 1 / 2 (replaces the row-1 stamp and the CU id)
+        if (threadIdx.x == 0 && slot == 1) p.trace[(size_t)v * 8 + 6] = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0 && slot == 2) p.trace[(size_t)v * 8 + 7] = __builtin_amdgcn_s_memtime();
+#else
+        if (threadIdx.x == 256 && slot == 5) p.trace[(size_t)v * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    };
+#else
+    auto trace = [&](int, int) {};
+#endif
+    stream_pp<BM, 256>(p.A, p.lda, p.ldb, p.N, p.K, n_tiles, smem, p.perm_b != 0, tile_of, init, epi, trace);
+}
+
+template <int EPI, int BM>
+int launch_pps_e(GemmParams& p, hipStream_t s) {
+    using C = PPCfg<BM, 256>;
+    constexpr int LDS = C::LDS_BYTES;
+    REID_MAX_LDS((mer_gemm_pps_kernel<EPI, BM>), LDS);
+    const int tiles = p.tiles_m * p.tiles_n;
+    int grid = reid_num_cus() & ~7;
+    if (grid > tiles) grid = tiles;                              // (then every workgroup has exactly one tile: v + grid >= tiles)
+#ifdef REID_GEMM_TRACE
+    p.trace = g_gemm_trace;
+#endif
+    hipLaunchKernelGGL((mer_gemm_pps_kernel<EPI, BM>), dim3(grid), dim3(C::NT), LDS, s, p);
+    REID_CHECK_LAUNCH("reid_mer_gemm");
+    return REID_OK;
+}
+
+
 template <int EPI, int BM>
 int launch_pp_e(GemmParams& p, hipStream_t s) {
     using C = PPCfg<BM, 256>;
@@ -551,6 +633,24 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
 #ifdef REID_GEMM_TRACE
     p.trace = g_gemm_trace;
 #endif
+    // persistent stream form (default where it applies; REID_GEMM_PERSIST=0 keeps one tile per workgroup)
+    const bool persist = reid_knob(KNOB_GEMM_PERSIST) != 0 && p.K2 == 0 && p.K >= 192 && (reid_num_cus() & ~7) >= 8 &&
+                         (p.epi == EPI_PLAIN16 || p.epi == EPI_RES32 ||
+                          (reid_knob(KNOB_GEMM_PERSIST) == 2 && (p.epi == EPI_GELU2 || p.epi == EPI_GELU2D)));
+    // (r03, tools/bench_gemm_shapes.py, profiles/r03_gemm_pps2.log: q|k|v 195 -> 183 us, q|k|v backward 157 -> 151, fc1 backward 207 -> 202,
+    //  residual shapes unchanged; the GELU shapes are 2 % SLOWER persistent (327 -> 334 us: their 6 + 3.5 us VALU-bound epilogue dominates the
+    //  tile boundary and a static tile sequence cannot rebalance it), so they stay one tile per workgroup unless REID_GEMM_PERSIST=2)
+    if (persist) {
+#define REID_PPS_CASE(E) case E: return bm == 224 ? launch_pps_e<E, 224>(p, s) : launch_pps_e<E, 256>(p, s);
+        switch (p.epi) {
+            REID_PPS_CASE(EPI_PLAIN16)
+            REID_PPS_CASE(EPI_RES32)
+            REID_PPS_CASE(EPI_GELU2)
+            REID_PPS_CASE(EPI_GELU2D)
+            default: break;
+        }
+#undef REID_PPS_CASE
+    }
 #define REID_PP_CASE(E) case E: return bm == 224 ? launch_pp_e<E, 224>(p, s) : launch_pp_e<E, 256>(p, s);
     switch (p.epi) {
         REID_PP_CASE(EPI_PLAIN16)

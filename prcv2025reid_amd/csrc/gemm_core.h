@@ -397,4 +397,189 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
     if (wm == 0) bar();                                                      // re-align the two wave rows
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the ping-pong loop: one workgroup per CU walks output tiles v = blockIdx.x, + gridDim.x, ... and the K-tile
+// stream never stops at a tile boundary: while a tile's last two K-tiles are multiplied, K-tiles 0 and 1 of the NEXT tile are
+// already being staged (they play the role of K-tiles nk and nk + 1 of the stream), so a tile's first MFMA phase starts right
+// after its predecessor's epilogue -- no first-operand round trip (~2 us) and no workgroup dispatch (~1 us) per tile.
+//
+// What makes this safe on gfx9's single in-order vmcnt (r02's persistent attempts lost to it): no VGPR-destination global load
+// and no scratch access sits between LDS-DMA issue and the counted waits inside the K loop; the epilogue's own loads / stores are
+// issued AFTER the prefetch of K-tile 1' and are older than K-tile 2' only, whose wait (vmcnt(4) in the next tile's first K-tile)
+// comes a whole MFMA phase later, when stores issued ~1 us earlier have long been acknowledged (0.4 us, r02 trace).  The tile
+// sequence is static (no queue word to load), the bias enters through the accumulator init as before.
+// Requirements: K a multiple of 64 with K >= 192 (nk >= 3), no low-rank K extension (merged weights), gridDim.x a multiple of 8.
+//   tile_of(v, m0, m_end, n0, Bw): geometry of tile v;  init_acc(n0);  epilogue(m0, m_end, n0)  (may use no LDS).
+template <int BM, int BN, typename TileOf, typename InitAcc, typename Epilogue, typename Trace>
+__device__ __forceinline__ void stream_pp(const bf16_t* __restrict__ A, int lda, int ldb, int N, int K, int n_tiles, char* smem,
+                                          bool perm_b, TileOf tile_of, InitAcc init_acc, Epilogue epilogue, Trace trace) {
+    using C = PPCfg<BM, BN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = K >> 6;
+    const int rl = lane >> 3, cl = lane & 7;
+    const bool a_last = 12 + wn < C::A_INSTR;                                  // wave-uniform (224-row tile: waves 2, 3 skip j = 3)
+
+    // geometry (scalars) of a tile and the per-lane source offsets of the tile whose K-tiles are being STAGED
+    int m0 = 0, m_end = 0, n0 = 0;
+    const bf16_t* Bt = nullptr;                                                // geometry: weight matrix of (m0, n0)'s row group
+    const bf16_t* Bw = nullptr;                                                // staging: weight matrix the offsets below refer to
+    uint32_t offA[4], offB[2][2];
+    auto set_offsets = [&]() {
+        Bw = Bt;
+        // lane id recomputed here (v_mbcnt) instead of kept live across the K loop: hipcc spilled the hoisted lane constants to scratch
+        // and reloaded them at this point -- a VMEM reload in the middle of the counted LDS-DMA stream
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int rl = ln >> 3, cl = ln & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 4 + wn) * 8 + rl;
+            int ga = m0 + C::RW * wm + r;
+            ga = ga < m_end - 1 ? ga : m_end - 1;
+            offA[j] = (uint32_t)ga * (uint32_t)lda * 2u + (uint32_t)swz(r, cl) * 16u;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (j * 8 + wave) * 8 + rl;
+                const int rb = 128 * h + r;
+                int gb = n0 + (perm_b ? perm32(rb) : rb);
+                gb = gb < N - 1 ? gb : N - 1;
+                offB[h][j] = (uint32_t)gb * (uint32_t)ldb * 2u + (uint32_t)swz(r, cl) * 16u;
+            }
+    };
+    auto stage_a = [&](int t, int buf) {
+        char* dst = smem + buf * C::BUF_BYTES + wm * C::HALF_BYTES;
+        const char* src = (const char*)A + (size_t)t * 128;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[j]), (lptr_t)(dst + (j * 4 + wn) * 8 * 128), 16, 0, 0);
+        if (C::A_INSTR == 16 || a_last)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[3]), (lptr_t)(dst + (12 + wn) * 8 * 128), 16, 0, 0);
+    };
+    auto stage_b = [&](int t, int buf) {
+        const char* src = (const char*)Bw + (size_t)t * 128;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + offB[h][j]),
+                                                 (lptr_t)(smem + buf * C::BUF_BYTES + (2 + h) * C::HALF_BYTES + (j * 8 + wave) * 8 * 128), 16, 0, 0);
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 128 + ((swz(frow, ks * 4 + fq)) << 4);
+    const int a_base = wm * C::HALF_BYTES;
+    const int b_base = (2 + (wn >> 1)) * C::HALF_BYTES + (wn & 1) * 64 * 128;
+    f32x4 acc[4][C::TM];
+    bf16x8 af[4][2], bfr[2][2][2];
+    auto read_a = [&](int buf, int a) {
+        const char* base = smem + buf * C::BUF_BYTES + a_base + a * 64 * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (a == 1 && i >= C::TM1) break;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(base + i * 16 * 128 + foff[ks]);
+        }
+    };
+    auto read_b = [&](int buf) {
+        const char* base = smem + buf * C::BUF_BYTES + b_base;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bfr[b][j][ks] = *(const bf16x8*)(base + (b * 32 + j * 16) * 128 + foff[ks]);
+    };
+    auto half = [&](auto a_c) {
+        constexpr int a = decltype(a_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < (a == 0 ? C::TM0 : C::TM1); ++i)
+                        acc[2 * b + j][4 * a + i] = mfma16(bfr[b][j][ks], af[i][ks], acc[2 * b + j][4 * a + i]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    // one K-tile of the stream; `st` >= 0: K-tile index (of the tile described by offA / offB / Bw) staged into the buffer being
+    // freed, st < 0: nothing left to stage (the stream ends)
+    auto ktile = [&](int cur, int st) {
+        read_a(cur, 0); read_b(cur);
+        pp_wait_lgkm0(); bar();
+        half(I0{}); bar();
+        read_a(cur, 1);
+        if (st >= 0) { stage_b(st, cur); pp_wait_vm4(); } else { pp_wait_vm0(); }
+        pp_wait_lgkm0(); bar();
+        if (st >= 0) stage_a(st, cur);
+        half(I1{}); bar();
+    };
+    auto ktile_fast = [&](int cur, int st) {                                 // steady state: one branch-free basic block
+        read_a(cur, 0); read_b(cur);
+        pp_wait_lgkm0(); bar();
+        half(I0{}); bar();
+        read_a(cur, 1);
+        stage_b(st, cur); pp_wait_vm4();
+        pp_wait_lgkm0(); bar();
+        stage_a(st, cur);
+        half(I1{}); bar();
+    };
+
+    int v = blockIdx.x;
+    tile_of(v, m0, m_end, n0, Bt);
+    set_offsets();
+    stage_b(0, 0); stage_a(0, 0);
+    stage_b(1, 1); stage_a(1, 1);
+    if (C::A_INSTR == 16 || a_last) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    bar();
+    int cur = 0;
+    for (;;) {
+        // Inside a tile wave row 1 runs ONE BARRIER behind row 0 (the ping-pong); around the epilogue the rows are re-aligned (one extra
+        // barrier each) so that both rows store at the same time -- without it row 1's last barrier would wait for row 0's whole epilogue
+        // and the two epilogues would run one after the other.
+        if (wm == 1) bar();
+        const int cm0 = m0, cm_end = m_end, cn0 = n0;                        // the tile being COMPUTED (scalars)
+        trace(v, 0);
+        init_acc(acc, cn0);
+        trace(v, 1);
+        // geometry of the NEXT tile now, at the start of the K loop: its scalar loads (tile table in the kernel arguments) and integer
+        // divisions have a whole K loop to complete; done at the switch point they held every wave for 0.8-1.5 us (r03 trace)
+        // (the 256-row tile has no registers to spare for four more live scalars -- the compiler spills to scratch, and a scratch reload
+        //  inside the counted LDS-DMA stream is worse than the stall: there the geometry is computed at the switch point)
+        constexpr bool EARLY = BM < 256;
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < n_tiles;                                  // workgroup-uniform
+        if (EARLY && has_next) tile_of(vn, m0, m_end, n0, Bt);
+        for (int T = 0; T + 2 < nk; ++T) { ktile_fast(cur, T + 2); cur ^= 1; }
+        trace(v, 2);
+        if (!EARLY && has_next) tile_of(vn, m0, m_end, n0, Bt);
+        if (has_next) set_offsets();                                         // from here on the staged K-tiles belong to the next tile
+        trace(v, 3);
+        ktile(cur, has_next ? 0 : -1); cur ^= 1;
+        ktile(cur, has_next ? 1 : -1); cur ^= 1;
+        if (wm == 0) bar();
+        trace(v, 4);
+        epilogue(acc, cm0, cm_end, cn0);
+        trace(v, 5);
+        if (!has_next) break;
+        v = vn;
+    }
+}
+
+
 }  // namespace gemmcore
