@@ -16,7 +16,7 @@ identities).  N > 1: configs[2] (P=32, K=4 PER GPU, same model; weak scaling), a
 value of that same per-GPU workload measured on rank 0 alone (`n1_same_workload`).  Inputs are resident in HBM.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (the MER GEMM: mer_gemm_pp_kernel / mer_gemm_kernel<128,128,2,2>, bf16 MFMA): algorithmic FLOPs of every launch in
+  roofline      -- dominant kernel (the MER GEMM: mer_gemm_pps_kernel / mer_gemm_pp_kernel / mer_gemm_kernel<128,128,2,2>, bf16 MFMA): algorithmic FLOPs of every launch in
                    the timed region / its duration measured with HIP events on the launch stream
   flavors       -- step time of BOTH 16-bit operand flavors (bf16 = headline, f16) on the same workload
   parity        -- per flavor, HIP vs the CPU oracle on the full-size batch of this workload (regularisers off): per-modality
@@ -73,22 +73,31 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = 'r02_pmc_traffic.json'
+PMC_FILE = 'r03_pmc_traffic.json'
+# kernels the roofline objects are about: the committed PMC summary must have been collected on a tree that dispatches kernels of
+# these names, or the traffic figure is refused (null + a note) instead of silently describing other code
+GEMM_KERNELS = ('mer_gemm_pps_kernel', 'mer_gemm_pp_kernel', 'mer_gemm_kernel<128, 128, 2, 2')
+LN_KERNELS = ('ln_bwd_kernel<true',)
 
 
-def pmc_traffic(*prefixes):
-    """Launch-weighted HBM bytes per launch of the kernels whose name starts with one of `prefixes`, from the committed PMC summary
-    (collected with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide
-    prescribes)."""
+def pmc_traffic(prefixes, required=None):
+    """(launch-weighted HBM bytes per launch of the kernels whose name starts with one of `prefixes`, note) from the committed PMC summary
+    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the microarch guide prescribes;
+    tools/pmc_collect.sh).  Every name of `required` must occur in the file: a summary made before a kernel was renamed or replaced no
+    longer describes the dispatched code and is refused."""
     path = os.path.join(ROOT, 'profiles', PMC_FILE)
     if not os.path.exists(path):
-        return None
+        return None, f'profiles/{PMC_FILE} not collected'
     d = json.load(open(path))
+    missing = [r for r in (required or prefixes) if not any(k.startswith(r) for k in d)]
+    if missing:
+        return None, f'profiles/{PMC_FILE} has no kernel named {missing}: stale summary refused'
     ks = [k for k in d if any(k.startswith(p) for p in prefixes)]
     n = sum(d[k]['launches'] for k in ks)
     if n == 0:
-        return None
-    return sum(d[k]['traffic_bytes_per_launch'] * d[k]['launches'] for k in ks) / n
+        return None, 'no launches'
+    return sum(d[k]['traffic_bytes_per_launch'] * d[k]['launches'] for k in ks) / n, \
+        f'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/{PMC_FILE})'
 
 
 def cpu_baseline():
@@ -543,18 +552,24 @@ def main():
     if prof:
         fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
-        res['roofline'] = {'kernel': 'mer_gemm_pp_kernel<EPI> (256x256 ping-pong tile) + mer_gemm_kernel<128,128,2,2,EPI> (the same MER GEMM; tile chosen per shape)',
+        traffic, tnote = pmc_traffic(GEMM_KERNELS)
+        res['roofline'] = {'kernel': 'the MER GEMM: mer_gemm_pps_kernel<EPI, BM> (persistent 256x256 / 224x256 ping-pong tiles: plain and residual epilogues), '
+                                     'mer_gemm_pp_kernel<EPI, BM> (same tiles, one per workgroup: GELU / multiply-by-derivative epilogues), '
+                                     'mer_gemm_kernel<128,128,2,2,EPI> (short-K narrow-N shapes); merged per-modality weights, row groups',
                            'bound': 'mfma', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': pmc_traffic('mer_gemm_pp_kernel', 'mer_gemm_kernel<128, 128, 2, 2'),
-                           'traffic_note': f'HBM bytes per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this command (profiles/{PMC_FILE}); null if not collected',
+                           'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_note': tnote,
                            'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
                            'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
-                           'flops_per_launch_avg': fl / len(prof)}
+                           'flops_per_launch_avg': fl / len(prof),
+                           'flops_counted': '2*M*N*K per launch (merged weights: no low-rank K extension, no padded columns)',
+                           'clock_note': 'in-kernel shader clock under this load 1.86-1.90 GHz (profiles/r03_gemm_clock.log): the dense bf16 MFMA rate '
+                                         'at that clock is 1.96 PFLOP/s; `peak` stays the 2.4 GHz figure of the microarch guide'}
     if ln_prof:
         nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
         gbs = nb / (ms * 1e-3) / 1e9
+        traffic, tnote = pmc_traffic(LN_KERNELS)
         res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                               'frac': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('ln_bwd_kernel<true'), 'launches': len(ln_prof),
+                               'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
     if world > 1:

@@ -106,32 +106,54 @@ class DataParallel:
         return [p for n, p in self.model.named_parameters()
                 if p.requires_grad and not (n.startswith('clip_encoder.') or n.startswith('null_tokens.'))]
 
+    def _small_bucket(self):
+        """ONE flat fp32 buffer holding the gradients of every small trainable tensor (null tokens first, then the head), with each
+        ``p.grad`` a VIEW into it: the step then needs two collectives (LoRA arena, this bucket) and no cat / copy-back of ~40
+        tensors.  Rebuilt (current values copied in) whenever somebody replaced a ``.grad`` tensor."""
+        small = [p for p in self.encoder_side_params() if p.numel() < (1 << 16)]
+        n_sum = len(small)
+        small += self.head_params()
+        b = getattr(self, '_bucket', None)
+        ok = b is not None and len(b['params']) == len(small) and all(a is c for a, c in zip(b['params'], small)) and \
+            all(p.grad is not None and p.grad.data_ptr() == ptr for p, ptr in zip(small, b['ptrs']))
+        if ok:
+            return b
+        offs, o = [], 0
+        for p in small:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4                      # 16-byte aligned slices (FusedAdamW's requirement)
+        dev = small[0].device if small else torch.device('cpu')
+        flat = torch.zeros(max(o, 4), dtype=torch.float32, device=dev)
+        ptrs = []
+        for p, off in zip(small, offs):
+            view = flat[off:off + p.numel()].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+            ptrs.append(view.data_ptr())
+        head_off = offs[n_sum] if n_sum < len(small) else o
+        self._bucket = dict(params=small, ptrs=ptrs, flat=flat, head=flat[head_off:o], n=o)
+        return self._bucket
+
     def reduce_grads(self):
         """Encoder-side gradients are per-rank partial sums -> all-reduce(SUM).  Head gradients are mathematically identical
         on every rank, but the head kernels reduce with fp32 atomics (BN-neck statistics, LayerNorm dgamma/dbeta), so their
         last bits differ from rank to rank; left alone the replicas would drift apart (Adam amplifies differences on
-        near-zero gradients).  They are therefore AVERAGED in the same small bucket: every rank steps with the same bits."""
+        near-zero gradients).  They are therefore AVERAGED: every rank steps with the same bits.
+        Two collectives per step: the flat LoRA arena (its own bucket) and the flat small-tensor bucket (null tokens summed,
+        head pre-scaled by 1 / world so that the SUM is the average)."""
         if self.world == 1:
             return
-        small, scale = [], []
+        b = self._small_bucket()
         for p in self.encoder_side_params():
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
             if p.numel() >= (1 << 16):
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)     # the flat LoRA arena: one bucket
-            else:
-                small.append(p); scale.append(1.0)
-        for p in self.head_params():
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            small.append(p); scale.append(1.0 / self.world)
-        if small:
-            flat = torch.cat([p.grad.reshape(-1) * s if s != 1.0 else p.grad.reshape(-1) for p, s in zip(small, scale)])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            o = 0
-            for p in small:
-                n = p.numel()
-                p.grad.copy_(flat[o:o + n].view_as(p.grad)); o += n
+        if b['n'] > 0:
+            if b['head'].numel():
+                b['head'].mul_(1.0 / self.world)
+            dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
 
     def params_in_sync(self) -> float:
         """max over parameters of (max over ranks - min over ranks) of the parameter values: 0.0 when the replicas agree

@@ -80,10 +80,17 @@ class GalleryIndex:
 
 
 def cmc_from_topk(topk_idx: torch.Tensor, q_pids: torch.Tensor, g_pids: torch.Tensor, ks=(1, 5, 10)):
-    """CMC@k over queries that have a positive in the gallery (eval_mm_protocol.py:425-441)."""
-    hit = g_pids.to(topk_idx.device)[topk_idx.long()] == q_pids.to(topk_idx.device).view(-1, 1)
-    has_pos = (q_pids.to(topk_idx.device).view(-1, 1) == g_pids.to(topk_idx.device).view(1, -1)).any(dim=1)
+    """CMC@k over queries that have a positive in the gallery (eval_mm_protocol.py:425-441).  "Has a positive" is a lookup in the
+    gallery's identity histogram ([max pid + 1] counts), not an [Nq, Ng] comparison (2 GB at 10k x 200k)."""
+    dev = topk_idx.device
+    gp = g_pids.to(dev).long(); qp = q_pids.to(dev).long()
+    hit = gp[topk_idx.long().clamp_min(0)] == qp.view(-1, 1)
+    hit &= topk_idx >= 0                                  # (-1 = no entry: fewer than k gallery rows)
+    lo = int(min(int(gp.min()), int(qp.min()))) if gp.numel() and qp.numel() else 0
+    counts = torch.bincount(gp - lo, minlength=int(max(int(gp.max()), int(qp.max())) - lo + 1)) if gp.numel() else torch.zeros(1, device=dev)
+    has_pos = counts[qp - lo] > 0
+    n_pos = int(has_pos.sum())
     out = {}
     for k in ks:
-        out[f'R@{k}'] = float(hit[:, :k].any(dim=1)[has_pos].float().mean()) if bool(has_pos.any()) else 0.0
+        out[f'R@{k}'] = float(hit[:, :k].any(dim=1)[has_pos].float().mean()) if n_pos > 0 else 0.0
     return out

@@ -151,3 +151,27 @@ def test_oracle_rank_ties_break_by_index():
     ex = torch.zeros(1, 50, dtype=torch.bool); ex[0, 3] = True
     idx2, _ = O.topk_ranklist(G[3:4], G, 2, exclude=ex)
     assert idx2[0].tolist() == [7, 20]
+
+
+def test_cmc_from_topk_equals_bruteforce_definition():
+    """CMC@k over the queries that have a positive in the gallery (eval_mm_protocol.py:425-441); the histogram lookup must select the
+    same queries as the [Nq, Ng] comparison it replaced."""
+    import torch
+    from prcv2025reid_amd.retrieval import cmc_from_topk
+    g = torch.Generator().manual_seed(3)
+    Nq, Ng, k = 200, 3000, 10
+    g_pids = torch.randint(5, 400, (Ng,), generator=g)
+    q_pids = torch.randint(0, 450, (Nq,), generator=g)             # some queries have no positive at all
+    sim = torch.randn(Nq, Ng, generator=g)
+    topk = sim.topk(k, dim=1).indices.int()
+    topk[7, 5:] = -1                                               # a short list
+    got = cmc_from_topk(topk, q_pids, g_pids, ks=(1, 5, 10))
+    has_pos = (q_pids.view(-1, 1) == g_pids.view(1, -1)).any(dim=1)
+    assert 0 < int(has_pos.sum()) < Nq
+    for kk in (1, 5, 10):
+        hit = torch.zeros(Nq, dtype=torch.bool)
+        for i in range(Nq):
+            idx = topk[i, :kk]; idx = idx[idx >= 0].long()
+            hit[i] = bool((g_pids[idx] == q_pids[i]).any())
+        want = float(hit[has_pos].float().mean())
+        assert abs(got[f'R@{kk}'] - want) < 1e-7, (kk, got, want)

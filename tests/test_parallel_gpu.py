@@ -85,7 +85,24 @@ def _worker(rank, world, port, tmp):
     for _ in range(3):
         drv.step(images, tokens, masks, labels)
     spread = dp.params_in_sync()
-    torch.save({'spread': spread}, os.path.join(tmp, f's{rank}.pt'))
+    # gradient accumulation through the data-parallel driver (train.py:833-834,895: accum 2): the all-reduce and the optimizer run on
+    # every second micro-batch only; masks differ from rank to rank (mask_drop 0.3) and between the two micro-batches (rows reversed)
+    drv2 = StepDriver(dp, opt, accum_steps=2, adaptive_clip=True, dp=dp)
+    rev = torch.arange(n - 1, -1, -1)
+    images_b = {m: t[rev.to(t.device)] for m, t in images.items()}
+    masks_b = {m: t[rev] for m, t in masks.items()}
+    tokens_b = {k: v[rev.to(v.device)] for k, v in tokens.items()}
+    labels_b = labels[rev.to(labels.device)]
+    count0 = opt.step_count
+    for i in range(4):
+        if i % 2 == 0:
+            drv2.step(images, tokens, masks, labels)
+        else:
+            drv2.step(images_b, tokens_b, masks_b, labels_b)
+    spread2 = dp.params_in_sync()
+    torch.save({'spread': spread, 'spread_accum2': spread2, 'opt_steps_accum2': opt.step_count - count0,
+                'bucket_views': all(p.grad is not None and p.grad.data_ptr() == ptr for p, ptr in zip(dp._bucket['params'], dp._bucket['ptrs']))},
+               os.path.join(tmp, f's{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -118,7 +135,10 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
     assert torch.equal(outs[0]['lora'], outs[1]['lora'])                    # all-reduced: identical bits on both ranks
     assert abs(outs[0]['loss'] - outs[1]['loss']) <= 1e-6
     for r in range(world):
-        assert torch.load(os.path.join(str(tmp_path), f's{r}.pt'))['spread'] == 0.0
+        sr = torch.load(os.path.join(str(tmp_path), f's{r}.pt'))
+        assert sr['spread'] == 0.0
+        assert sr['spread_accum2'] == 0.0 and sr['opt_steps_accum2'] == 2      # four micro-batches = two optimizer steps, replicas identical
+        assert sr['bucket_views']                                              # small gradients live in ONE flat bucket (two collectives per step)
     print(f'  DP(2 ranks) loss {outs[0]["loss"]:.6f} vs single process {ref_loss:.6f}')
 
 
