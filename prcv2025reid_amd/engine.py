@@ -345,17 +345,27 @@ class Engine:
                 t = buf[name] = torch.empty(shape, **kw)
             return t
 
+        deferred = []
+
         def lora_down(calls):
-            """T = mask_modality(x . Acat^T) * (alpha/r) for the block's four linears: needed only by the backward pass (dB = dY^T T),
-            so it runs beside the main stream's GEMMs (same inputs, fresh in L2 / Infinity Cache) instead of in front of them."""
+            """T = mask_modality(x . Acat^T) * (alpha/r) for the block's four linears: needed only by the backward pass (dB = dY^T T).
+            Held back until the encoder is through (flush_lora_down): the 48 HBM-bound launches then run on the side stream beneath the
+            head / loss / head-backward section -- ~1.5 ms of tiny kernels that leave the chip idle -- instead of taking compute units
+            from the forward GEMMs and attention (their inputs are the saved activations, alive until the backward pass)."""
             if side is None:
                 for xin_, A_, T_, kw in calls:
                     ops.gemm(xin_, A_, T_, **kw)
                 return
+            deferred.extend(calls)
+
+        def flush_lora_down():
+            if not deferred:
+                return
             ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
             with torch.cuda.stream(side):
-                for xin_, A_, T_, kw in calls:
+                for xin_, A_, T_, kw in deferred:
                     ops.gemm(xin_, A_, T_, **kw)
+            deferred.clear()
 
         for l in range(a['vision_layers']):
             lp = f'{ce}vision_layers.{l}.'
@@ -392,6 +402,8 @@ class Engine:
                 T1 = torch.empty(Mr, Rp, **b16); T2 = torch.empty(Mr, Rp, **b16)
                 lora_down([(h, pk(l, 'qkv', 'A'), T, mk), (oin, pk(l, 'out', 'A'), To, mkr), (h2, pk(l, 'fc1', 'A'), T1, mkr),
                            (g, pk(l, 'fc2', 'A'), T2, mkr)])
+                if side is not None and os.environ.get('REID_LORA_DOWN_DEFER', '1') == '0':
+                    flush_lora_down()
             xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
             ops.gemm(g, we(l, 'fc2'), xn, bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi,
                      row_groups=rg)
@@ -404,6 +416,8 @@ class Engine:
                           row_index=None if self.cls_prune else idx)
         feats = torch.empty(n_img, a['fusion_dim'], **f32)
         ops.gemm(cls_h, W['vproj'], feats)
+        if os.environ.get('REID_LORA_DOWN_DEFER', '1') != '0':
+            flush_lora_down()
         state = dict(layers=saved, x_final=x, idx=idx, idxl=idxl, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
                      groups=groups, cls_prune=self.cls_prune, rg_full=rg_full, rg_cls=rg_cls) if save else None
         return feats, state
