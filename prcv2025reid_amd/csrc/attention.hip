@@ -276,33 +276,6 @@ __global__ __launch_bounds__(NT * 64, TWO_PASS ? 4 : 1) void attn_fwd_kernel(con
     }
 }
 
-// ------------------------------------------------------------------------------------------ backward: delta
-// delta[seq, head, q] = sum_d dO[q, d] * O[q, d]
-// one wave per token row; a 256-element chunk (4 heads) per instruction: 8-byte loads, 16 lanes per head
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
-    REID_T16_ENTER();
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long)p.n_seq * p.S) return;
-    const bf16_t* o = p.out + row * p.ldo;
-    const bf16_t* g = p.dout + row * p.ldo;
-    const long seq = row / p.S, q = row % p.S;
-    if (p.q_tiles > 0 && q >= p.q_tiles * 32) return;     // query rows that take no part
-    for (int h0 = 0; h0 < p.heads; h0 += 4) {
-        const int col = h0 * 64 + lane * 4;
-        float v = 0.f;
-        if (col < p.heads * 64) {
-            const bf16x4 a = *(const bf16x4*)(o + col), b = *(const bf16x4*)(g + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v += bf16_to_f32((bf16_t)a[e]) * bf16_to_f32((bf16_t)b[e]);
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        const int head = h0 + (lane >> 4);
-        if ((lane & 15) == 0 && head < p.heads) p.delta[(seq * p.heads + head) * p.S + q] = v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // Wave w owns key tile w (keys on the lane).  Per query tile: S = Q.K^T and dP = dO.V^T land as
 // [query rows (regs) x key columns (lanes)] and feed dV^T += dO^T.P and dK^T += Q^T.dS as B operands.
@@ -432,7 +405,23 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
         gf[ks] = gfrag(gb, p.ldo, qrow, 2 * ks, lane);
     }
     const size_t so = ((size_t)seq * p.heads + head) * p.S + qrow;
-    const float nl = -p.lse[so] * LOG2E, nd = -p.delta[so] * 0.125f;
+    const float nl = -p.lse[so] * LOG2E;
+    // delta[q] = sum_d dO[q, d] O[q, d], formed HERE from the dO fragments this wave holds anyway and the matching O fragments (a lane has
+    // 32 of the row's 64 products, lane ^ 32 the rest) and published for the dK/dV kernel, which is launched after this one: the separate
+    // delta kernel (one more pass over O and dO, 30-50 us per layer) is gone.
+    float dsum = 0.f;
+    {
+        const bf16_t* ob = p.out + (size_t)seq * p.S * p.ldo + head * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 of = gfrag(ob, p.ldo, qrow, 2 * ks, lane);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf(bf16_to_f32((bf16_t)gf[ks][j]), bf16_to_f32((bf16_t)of[j]), dsum);
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (qi < p.S && lane < 32) p.delta[so] = dsum;
+    const float nd = -dsum * 0.125f;
     __syncthreads();
     if (q0 >= p.S) return;
     if (p.q_tiles > 0 && wave >= p.q_tiles) {               // query tile left out: its dQ rows are exactly zero
@@ -510,13 +499,11 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS2 = 2 * NT * 32 * 128;
     REID_MAX_LDS((attn_bwd_dkv_kernel<NT>), LDS1);
     REID_MAX_LDS((attn_bwd_dq_kernel<NT>), LDS2);
-    const long rows = (long)p.n_seq * p.S;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, p);
-    REID_CHECK_LAUNCH("reid_attn_bwd(delta)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS1, s, p);
-    REID_CHECK_LAUNCH("reid_attn_bwd(dkv)");
+    // dQ first: it also produces delta (rows of the query tiles that take part), which the dK/dV kernel reads
     hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS2, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(dq)");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS1, s, p);
+    REID_CHECK_LAUNCH("reid_attn_bwd(dkv)");
     return REID_OK;
 }
 

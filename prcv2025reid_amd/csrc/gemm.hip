@@ -634,9 +634,14 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
     p.trace = g_gemm_trace;
 #endif
     // persistent stream form (default where it applies; REID_GEMM_PERSIST=0 keeps one tile per workgroup)
-    const bool persist = reid_knob(KNOB_GEMM_PERSIST) != 0 && p.K2 == 0 && p.K >= 192 && (reid_num_cus() & ~7) >= 8 &&
-                         (p.epi == EPI_PLAIN16 || p.epi == EPI_RES32 ||
-                          (reid_knob(KNOB_GEMM_PERSIST) == 2 && (p.epi == EPI_GELU2 || p.epi == EPI_GELU2D)));
+    // REID_GEMM_PERSIST bits: 1 = persistent form on; 2 = GELU epilogues too; 4 = multiply-by-derivative epilogue too (register-direct
+    // aux operand); 8 = the short-K narrow-N out-projection shapes on this tile as well.  Default 9.  In-step A/B (r03, bench.py, one box):
+    // 1: 33.15-33.25 ms/step, 9: 33.02, 13: 32.98-33.00, 5: 33.40 -- inside the step a persistent GEMM keeps its CUs for its whole duration,
+    // so the HBM-bound side-stream kernels cannot take compute units from it (q|k|v backward 263 -> 194 us in-step)
+    const int pk = reid_knob(KNOB_GEMM_PERSIST) < 0 ? 9 : reid_knob(KNOB_GEMM_PERSIST);
+    const bool persist = pk != 0 && p.K2 == 0 && p.K >= 192 && (reid_num_cus() & ~7) >= 8 &&
+                         (p.epi == EPI_PLAIN16 || p.epi == EPI_RES32 || ((pk & 2) && (p.epi == EPI_GELU2 || p.epi == EPI_GELU2D)) ||
+                          ((pk & 4) && p.epi == EPI_MULAUX));
     // (r03, tools/bench_gemm_shapes.py, profiles/r03_gemm_pps2.log: q|k|v 195 -> 183 us, q|k|v backward 157 -> 151, fc1 backward 207 -> 202,
     //  residual shapes unchanged; the GELU shapes are 2 % SLOWER persistent (327 -> 334 us: their 6 + 3.5 us VALU-bound epilogue dominates the
     //  tile boundary and a static tile sequence cannot rebalance it), so they stay one tile per workgroup unless REID_GEMM_PERSIST=2)
@@ -647,6 +652,7 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
             REID_PPS_CASE(EPI_RES32)
             REID_PPS_CASE(EPI_GELU2)
             REID_PPS_CASE(EPI_GELU2D)
+            REID_PPS_CASE(EPI_MULAUX)
             default: break;
         }
 #undef REID_PPS_CASE
@@ -812,7 +818,8 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
         // drains the prefetch at every tile start, and the loop carries ~40 spilled registers across tile boundaries.)
         const bool pp_ok = (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) && p.N % 256 == 0;
         const long tiles256 = (long)row_tiles(p, 256, false) * (p.N / 256);
-        const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536) && tiles256 >= reid_num_cus();
+        const bool small_too = reid_knob(KNOB_GEMM_PERSIST) < 0 || (reid_knob(KNOB_GEMM_PERSIST) & 8);     // out-projection shapes as well (see launch_pp)
+        const bool pp_shape = (p.K + p.K2 >= 1536 || p.N >= 1536 || small_too) && tiles256 >= reid_num_cus();
         if (pp_ok && (tile == 12 || tile == 14 || (tile == 0 && pp_shape && reid_knob(KNOB_GEMM_EPI) != 0 && pick_epilogue(p, 256) != EPI_GENERIC)))
             return launch_pp(p, s, tile);
     }
