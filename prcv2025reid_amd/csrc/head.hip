@@ -376,6 +376,7 @@ __global__ void eltwise_kernel(int op, const float* __restrict__ x, const float*
             case 3: r = gelu_erf_f(a); break;                          // gelu
             case 4: r = y[i] * dgelu_erf_f(a); break;                  // gelu backward
             case 5: r = a * y[i]; break;                               // mul
+            case 7: r = a >= alpha ? 1.0f / (1.0f - alpha) : 0.f; break;   // dropout multiplier from a uniform draw: keep iff u >= p
             default: r = isfinite(a) ? a : (a != a ? 0.f : (a > 0.f ? 1e4f : -1e4f)); break;   // 6: nan_to_num(0, 1e4, -1e4)
         }
         out[i] = r;
@@ -593,8 +594,8 @@ extern "C" int reid_ce_ls_bwd(const float* logits, int32_t ld, const int64_t* la
 }
 
 extern "C" int reid_eltwise_f32(int32_t op, const float* x, const float* y, float* out, int64_t n, float alpha, void* stream) {
-    REID_CHECK_ARG(x && out && n > 0 && op >= 0 && op <= 6, "reid_eltwise_f32: bad args");
-    REID_CHECK_ARG(y || op == 1 || op == 3 || op == 6, "reid_eltwise_f32: op %d needs a second operand", op);
+    REID_CHECK_ARG(x && out && n > 0 && op >= 0 && op <= 7, "reid_eltwise_f32: bad args");
+    REID_CHECK_ARG(y || op == 1 || op == 3 || op == 6 || op == 7, "reid_eltwise_f32: op %d needs a second operand", op);
     const long blocks = (n + 255) / 256;
     hipLaunchKernelGGL(eltwise_kernel, dim3((int)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, op, x, y, out, (long)n, alpha);
     REID_CHECK_LAUNCH("reid_eltwise_f32");

@@ -299,7 +299,7 @@ def cosine_topk_exact(Qf, Gf, k, scratch, out_idx, out_score, exclude_q=None, ex
 
 
 # ----------------------------------------------------------------------------------------- small fp32 head pieces
-ELT = {'add': 0, 'relu': 1, 'relu_bwd': 2, 'gelu': 3, 'gelu_bwd': 4, 'mul': 5, 'nan_to_num': 6}
+ELT = {'add': 0, 'relu': 1, 'relu_bwd': 2, 'gelu': 3, 'gelu_bwd': 4, 'mul': 5, 'nan_to_num': 6, 'keep_mask': 7}
 
 
 def eltwise(op, x, y=None, out=None, alpha=1.0):
