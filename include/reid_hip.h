@@ -133,6 +133,13 @@ int reid_gemm_tn(const void* X, const void* Y, float* C, int32_t M, int32_t P, i
 int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                        const float* beta, void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd,
                        int32_t rows, int32_t cols, float eps, void* stream);
+/* Residual add fused into the LayerNorm that follows it (models/clip_backbone.py:76 -> :82, :83 -> next block's :73):
+ *   x_out = x + row_scale[row / rows_per_img] * y        (x f32, y = the 16-bit branch output of reid_mer_gemm; row_scale NULL = 1:
+ *                                                         DropPath, clip_backbone.py:137-141);  h = LayerNorm(x_out) in 16 bits,
+ *   mean / rstd of x_out saved for the backward pass.  x_out may alias x. */
+int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t ldy, const float* row_scale, int32_t rows_per_img,
+                           float* x_out, int32_t ldxo, const float* gamma, const float* beta, void* h_bf16, int32_t ldh,
+                           float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
                        const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dx_bf16, int32_t lddx,

@@ -132,6 +132,70 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------- residual add + LayerNorm forward
+// x_out = x + scale[row / rows_per_img] * y (y = the 16-bit output of the out-projection / fc2 GEMM), h = LayerNorm(x_out).
+// Why: with the residual in the GEMM epilogue every tile read and wrote 4 bytes per element of fp32 while its matrix pipe idled
+// (all 256 workgroups reach their epilogues together: 117 MB per round, ~23 us at HBM speed -- the out-projection ran at 21 % of the
+// MFMA peak, r02 verdict); here the GEMM stores 2 bytes per element and this kernel, which streams x anyway, does the add.  Same
+// bytes in total (GEMM 1.5 + this 9 KB per row against 6 + 4.5), but all of them at streaming speed and none under an idle MFMA.
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
+                                                         const float* __restrict__ row_scale, int rows_per_img,
+                                                         float* __restrict__ xo, int ldxo, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16_t* __restrict__ hb, int ldh,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int cols, float eps) {
+    REID_T16_ENTER();
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const bf16_t* yr = y + (size_t)row * ldy;
+    const float sc = row_scale ? row_scale[row / rows_per_img] : 1.f;
+    const int nv = cols >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 a = *(const f32x4*)(xr + c * 4);
+            const bf16x4 b = *(const bf16x4*)(yr + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = fmaf(sc, bf16_to_f32((bf16_t)b[e]), a[e]);
+            *(f32x4*)(xo + (size_t)row * ldxo + c * 4) = v[i];
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mu = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / cols + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = *(const f32x4*)(gamma + c * 4);
+            const f32x4 b = *(const f32x4*)(beta + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+            *(uint2*)(hb + (size_t)row * ldh + c * 4) = uint2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm backward
 // Rows are walked with a grid stride so that, when the affine gradients are wanted, every wave keeps its dgamma / dbeta
 // partial sums in registers over all its rows and adds them to memory ONCE (one atomic per column per wave instead of one per
@@ -329,6 +393,21 @@ extern "C" int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* ro
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, row_index, gamma, beta,
                        (bf16_t*)y_bf16, y_f32, ldy, mean, rstd, rows, cols, eps);
     REID_CHECK_LAUNCH("reid_layernorm_fwd");
+    return REID_OK;
+}
+
+extern "C" int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t ldy, const float* row_scale,
+                                      int32_t rows_per_img, float* x_out, int32_t ldxo, const float* gamma, const float* beta,
+                                      void* h_bf16, int32_t ldh, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
+                                      void* stream) {
+    REID_CHECK_ARG(x && y_bf16 && x_out && gamma && beta && h_bf16, "reid_add_layernorm_fwd: null pointer");
+    REID_CHECK_ARG(!row_scale || rows_per_img > 0, "reid_add_layernorm_fwd: row_scale needs rows_per_img");
+    REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_add_layernorm_fwd: cols=%d unsupported", cols);
+    REID_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldxo % 4 == 0 && ldh % 4 == 0 && ldx >= cols && ldy >= cols && ldxo >= cols && ldh >= cols,
+                   "reid_add_layernorm_fwd: ld");
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)y_bf16, ldy, row_scale,
+                       rows_per_img, x_out, ldxo, gamma, beta, (bf16_t*)h_bf16, ldh, mean, rstd, rows, cols, eps);
+    REID_CHECK_LAUNCH("reid_add_layernorm_fwd");
     return REID_OK;
 }
 

@@ -367,10 +367,19 @@ class Engine:
                     ops.gemm(xin_, A_, T_, **kw)
             deferred.clear()
 
-        for l in range(a['vision_layers']):
+        # Residual adds live in the LayerNorm that follows them (reid_add_layernorm_fwd): the out-projection and fc2 GEMMs store their
+        # 16-bit branch output, the add + LN kernel streams x once.  LN1 of block l+1 is therefore produced at the end of block l.
+        add_ln = os.environ.get('REID_ADD_LN', '1') != '0'
+        L = a['vision_layers']
+        nxt = None
+        for l in range(L):
             lp = f'{ce}vision_layers.{l}.'
-            h = new('h', (M, d), b16); mean1 = new('m1', (M,), f32); rstd1 = new('r1', (M,), f32)
-            ops.layernorm_fwd(x, P[lp + 'ln1.weight'], P[lp + 'ln1.bias'], y_bf16=h, mean=mean1, rstd=rstd1)
+            if nxt is None:
+                h = new('h', (M, d), b16); mean1 = new('m1', (M,), f32); rstd1 = new('r1', (M,), f32)
+                ops.layernorm_fwd(x, P[lp + 'ln1.weight'], P[lp + 'ln1.bias'], y_bf16=h, mean=mean1, rstd=rstd1)
+            else:
+                h, mean1, rstd1 = nxt
+                nxt = None
             qkv = new('qkv', (M, 3 * d), b16)
             ops.gemm(h, we(l, 'qkv'), qkv, bias=W[('v', l, 'bqkv')], row_groups=rg_full)
             o = new('o', (M, d), b16); lse = new('lse', (n_img, heads, S), f32)
@@ -388,10 +397,17 @@ class Engine:
                 xin, oin = x, o
             mkr = dict(img_mod=img_mod, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=self.scaling)
             xm = new('xm', (Mr, d), f32)
-            ops.gemm(oin, we(l, 'out'), xm, bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=xin, row_scale=sa, rows_per_img=rpi,
-                     row_groups=rg)
             h2 = new('h2', (Mr, d), b16); mean2 = new('m2', (Mr,), f32); rstd2 = new('r2', (Mr,), f32)
-            ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
+            if add_ln and not last:
+                yb = buf.get('yb')
+                if yb is None:
+                    yb = buf['yb'] = torch.empty(M, d, **b16)
+                ops.gemm(oin, we(l, 'out'), yb, bias=P[lp + 'attn.out_proj.shared_linear.bias'], row_groups=rg)
+                ops.add_layernorm_fwd(xin, yb, xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], h2, mean2, rstd2, row_scale=sa, rows_per_img=rpi)
+            else:
+                ops.gemm(oin, we(l, 'out'), xm, bias=P[lp + 'attn.out_proj.shared_linear.bias'], R=xin, row_scale=sa, rows_per_img=rpi,
+                         row_groups=rg)
+                ops.layernorm_fwd(xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], y_bf16=h2, mean=mean2, rstd=rstd2)
             u = new('u', (Mr, ff), b16) if save else None      # holds gelu'(pre-activation): the backward epilogue is one multiply
             g = new('g', (Mr, ff), b16)
             ops.gemm(h2, we(l, 'fc1'), g, bias=P[lp + 'mlp.fc1.shared_linear.bias'], act='gelu_dsave' if save else 'gelu', C2=u,
@@ -405,8 +421,17 @@ class Engine:
                 if side is not None and os.environ.get('REID_LORA_DOWN_DEFER', '1') == '0':
                     flush_lora_down()
             xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
-            ops.gemm(g, we(l, 'fc2'), xn, bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi,
-                     row_groups=rg)
+            if add_ln and not last and l + 1 < L:
+                np_ = f'{ce}vision_layers.{l + 1}.'
+                ops.gemm(g, we(l, 'fc2'), yb, bias=P[lp + 'mlp.fc2.shared_linear.bias'], row_groups=rg)
+                # (eval keeps two h buffers: the next block's h is written while nothing reads this block's any more, but a fresh
+                #  name keeps the lifetime obvious)
+                nxt = (new('h' + str((l + 1) & 1), (M, d), b16), new('m1' + str((l + 1) & 1), (M,), f32), new('r1' + str((l + 1) & 1), (M,), f32))
+                ops.add_layernorm_fwd(xm, yb, xn, P[np_ + 'ln1.weight'], P[np_ + 'ln1.bias'], nxt[0], nxt[1], nxt[2], row_scale=sm_,
+                                      rows_per_img=rpi)
+            else:
+                ops.gemm(g, we(l, 'fc2'), xn, bias=P[lp + 'mlp.fc2.shared_linear.bias'], R=xm, row_scale=sm_, rows_per_img=rpi,
+                         row_groups=rg)
             if save:
                 saved.append(dict(x=x, h=h, mean1=mean1, rstd1=rstd1, T=T, qkv=qkv, o=o, lse=lse, To=To, xm=xm, h2=h2,
                                   mean2=mean2, rstd2=rstd2, T1=T1, u=u, g=g, T2=T2, sa=sa, sm=sm_, cls=last, o_rows=oin))

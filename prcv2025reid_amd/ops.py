@@ -108,6 +108,13 @@ def layernorm_fwd(x, gamma, beta, y_bf16=None, y_f32=None, mean=None, rstd=None,
                                    y.stride(0), ptr(mean), ptr(rstd), rows, x.shape[1], C.c_float(eps), stream_ptr()))
 
 
+def add_layernorm_fwd(x, y, x_out, gamma, beta, h, mean=None, rstd=None, row_scale=None, rows_per_img=0, eps=1e-5):
+    """x_out = x + row_scale[row // rows_per_img] * y;  h = LayerNorm(x_out) (16-bit);  see reid_add_layernorm_fwd."""
+    check(lib().reid_add_layernorm_fwd(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(row_scale), rows_per_img, ptr(x_out), x_out.stride(0),
+                                       ptr(gamma), ptr(beta), ptr(h), h.stride(0), ptr(mean), ptr(rstd), x.shape[0], x.shape[1],
+                                       C.c_float(eps), stream_ptr()))
+
+
 _ln_profile = None
 
 

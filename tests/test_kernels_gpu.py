@@ -268,6 +268,34 @@ def test_layernorm(ops, rows, cols):
     assert rel_err(dxs, xr.grad) < 2e-5
 
 
+@pytest.mark.parametrize('rows,rpi,cols,scaled', [(197 * 3, 197, 768, True), (64, 1, 768, False), (50 * 5 + 3, 50, 512, True), (8, 4, 64, True)])
+def test_add_layernorm(ops, rows, rpi, cols, scaled):
+    """x_out = x + scale[image] * y (fp32 add of the 16-bit branch output), h = LN(x_out): clip_backbone.py:76/:83 fused into the
+    LayerNorm that follows.  The sum is bit-exact (one fma per element); LN as test_layernorm."""
+    g = torch.Generator(device='cuda').manual_seed(rows + cols)
+    x = torch.randn(rows, cols, device='cuda', generator=g) * 2 + 0.5
+    y = bf(torch.randn(rows, cols, device='cuda', generator=g))
+    n_img = (rows + rpi - 1) // rpi
+    sc = (torch.rand(n_img, device='cuda', generator=g) > 0.3).float() / 0.7 if scaled else None
+    gamma = 1 + 0.1 * torch.randn(cols, device='cuda', generator=g); beta = 0.1 * torch.randn(cols, device='cuda', generator=g)
+    xo = torch.empty_like(x); h = torch.empty(rows, cols, device='cuda', dtype=T16())
+    mean = torch.empty(rows, device='cuda'); rstd = torch.empty(rows, device='cuda')
+    ops.add_layernorm_fwd(x, y, xo, gamma, beta, h, mean, rstd, row_scale=sc, rows_per_img=rpi if scaled else 0)
+    if scaled:
+        srow = sc.repeat_interleave(rpi)[:rows, None]
+        want = torch.addcmul(x.double(), srow.double(), y.double()).float()
+    else:
+        want = x + y.float()
+    assert float((xo - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    ref = torch.nn.functional.layer_norm(xo, (cols,), gamma, beta, 1e-5)
+    assert rel_err(h.float(), ref) < 1e-2
+    assert rel_err(mean, xo.mean(1)) < 1e-5 and rel_err(rstd, (xo.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    # in place: x_out aliasing x
+    x2 = x.clone()
+    ops.add_layernorm_fwd(x2, y, x2, gamma, beta, h, row_scale=sc, rows_per_img=rpi if scaled else 0)
+    assert torch.equal(x2, xo)
+
+
 def _attn_ref(qkv, n_seq, S, heads, causal, key_mask):
     d = heads * 64
     q, k, v = [t.view(n_seq, S, heads, 64).transpose(1, 2) for t in qkv.split(d, dim=1)]
