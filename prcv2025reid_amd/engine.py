@@ -340,9 +340,9 @@ class Engine:
         def new(name, shape, kw):
             if save:
                 return torch.empty(shape, **kw)
-            t = buf.get(name)
+            t = buf.get((name, shape))                       # (the class-row pass of the last block has its own, smaller set)
             if t is None:
-                t = buf[name] = torch.empty(shape, **kw)
+                t = buf[(name, shape)] = torch.empty(shape, **kw)
             return t
 
         deferred = []
@@ -365,6 +365,9 @@ class Engine:
             with torch.cuda.stream(side):
                 for xin_, A_, T_, kw in deferred:
                     ops.gemm(xin_, A_, T_, **kw)
+                    # (both normally live until the backward pass; if the graph is dropped instead, the allocator must not hand
+                    #  their blocks out while these launches are pending)
+                    T_.record_stream(side); xin_.record_stream(side)
             deferred.clear()
 
         # Residual adds live in the LayerNorm that follows them (reid_add_layernorm_fwd): the out-projection and fc2 GEMMs store their

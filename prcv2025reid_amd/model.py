@@ -266,11 +266,16 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
     def _vision_apply(self, mods, images):
         """VisionEncodeFn with the backbone tensors as extra autograd inputs only when one of them trains
         (freeze_backbone=False); the reference default (train.py:1418-1425) passes none."""
+        if not torch.is_grad_enabled():
+            # No graph will be built: run the executor forward-only.  (Function.apply fills ctx.needs_input_grad from the inputs'
+            # requires_grad flags whatever the grad mode, so going through VisionEncodeFn here would save every activation and
+            # queue the adapter-gradient side products on the side stream -- whose outputs die with the discarded ctx while
+            # those kernels are still pending: their blocks were handed to the head's tensors and overwritten under them.)
+            return self.engine.vision_forward(list(zip(tuple(mods), images)), save=False)[0]
         dense = []
-        if torch.is_grad_enabled():
-            keys = self.engine.vision_dense_keys()
-            if any(self._ref[k].requires_grad for k in keys):
-                dense = [self._ref[k] for k in keys]
+        keys = self.engine.vision_dense_keys()
+        if any(self._ref[k].requires_grad for k in keys):
+            dense = [self._ref[k] for k in keys]
         return VisionEncodeFn.apply(self.engine, tuple(mods), self.lora_arena, len(images), *images, *dense)
 
     # ------------------------------------------------------------------ encoders

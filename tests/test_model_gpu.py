@@ -569,3 +569,51 @@ def test_config2_full_size_vs_oracle(flavor):
         assert v <= (bounds.NORTH_STAR_TOL if flavor == 'f16' else bounds.loss_bound(flavor, B, D, kl[k])), (k, v)
     L['total_loss'].backward()
     assert torch.isfinite(model.lora_arena.grad).all() and float(model.lora_arena.grad.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Forward-only use (torch.no_grad(): evaluation, the benchmark's parity leg).  autograd.Function.apply reports the inputs'
+# requires_grad flags in ctx.needs_input_grad whatever the grad mode, so the executor has to be told not to save activations and
+# not to queue the adapter-gradient side products -- their outputs die with the discarded ctx while the side stream still writes
+# them, and the head's tensors get the freed blocks (r03: tail rows of modality_features / logits overwritten in ~70 % of the
+# second models of a process).
+def test_no_grad_forward_saves_nothing_and_is_reproducible():
+    from prcv2025reid_amd.config import TrainingConfig, arch_of
+    from prcv2025reid_amd.model import CLIPBasedMultiModalReIDModel, apply_reference_freeze
+    from prcv2025reid_amd.synthetic import synthetic_batch
+    from prcv2025reid_amd.weights import seeded_state
+    C = 400
+    state = batch = None
+    for flavor in ('bf16', 'f16', 'bf16'):                  # several models in one process: the allocator's blocks are recycled
+        cfg = TrainingConfig(device='cuda', mer_lora_rank=8, contrastive_weight=0.1, compute_dtype=flavor, init='seeded',
+                             drop_path=0.0, modality_dropout=0.0, dropout_rate=0.0, fusion_dropout=0.0, sdm_dropout=0.0)
+        model = CLIPBasedMultiModalReIDModel(cfg)
+        model.set_num_classes(C)
+        if state is None:
+            state = seeded_state(arch_of(cfg), C, 0)
+            batch = synthetic_batch(16, 4, model.arch, seed=1000, num_classes=C)
+        model.load_state_dict(state)
+        apply_reference_freeze(model)
+        model.set_epoch(2); model.train()
+        seen = []
+        inner = model.engine.vision_forward
+        model.engine.vision_forward = lambda groups, save, drop_scales=None: (seen.append(save), inner(groups, save, drop_scales))[1]
+        labels = batch['person_id'].cuda()
+        outs = []
+        for rep in range(4):
+            with torch.no_grad():
+                out = model(images={m: t.cuda() for m, t in batch['images'].items()}, texts=batch['texts'],
+                            modality_masks=batch['modality_mask'])
+                model.compute_loss(out, labels)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert seen == [False] * 4, seen
+        assert model.engine._side is None                    # no adapter-gradient stream was ever created
+        for rep in range(1, 4):
+            for k in ('features', 'bn_features', 'logits'):
+                assert torch.equal(outs[rep][k], outs[0][k]), (flavor, rep, k)
+            for g in ('raw_modality_features', 'modality_features'):
+                for m in outs[0][g]:
+                    assert torch.equal(outs[rep][g][m], outs[0][g][m]), (flavor, rep, g, m)
+        del model, outs, out
+        torch.cuda.empty_cache()
