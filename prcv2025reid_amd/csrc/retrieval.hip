@@ -406,6 +406,12 @@ extern "C" int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k) {
 }
 
 namespace {
+// fast form of phase C for k <= STREAM_K_MAX (defined with the sorting helpers of the streaming section below)
+int launch_select_fast(const float* Qf, const float* Gf, int D, const int32_t* exq, const int32_t* exg, const int32_t* cand_idx,
+                       const float* cand_score, const int32_t* cand_cnt, int cap, int k, int32_t* out_idx, float* out_score, int Nq,
+                       hipStream_t s);
+constexpr int SELECT_FAST_K_MAX = 32;
+
 template <int BM, int BN, int WM, int WN>
 int launch_filter(TopkParams p, hipStream_t s) {
     using C = Cfg<BM, BN, WM, WN>;
@@ -468,11 +474,17 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
         int rc;
         if (tile == 1) rc = launch_filter<256, 128, 4, 2>(p, s);
         else if (tile == 3) rc = launch_filter<256, 256, 2, 4>(p, s);
+        else if (tile == 4) rc = launch_filter<128, 256, 2, 4>(p, s);
+        else if (tile == 5) rc = launch_filter<64, 256, 1, 4>(p, s);
+        else if (tile == 6) rc = launch_filter<64, 128, 1, 4>(p, s);
+        else if (tile == 2 && Nq <= 64 && Ng >= 1024) rc = launch_filter<64, 256, 1, 4>(p, s);   // few queries: half the query panel staged per gallery row (r03: 123 -> 105 us at 5-32 queries x 200k)
         else if (tile == 0 || Nq < 256 || Ng < 1024) rc = launch_filter<128, 128, 2, 2>(p, s);
         else rc = launch_filter<128, 256, 2, 4>(p, s);
         if (rc) return rc;
     }
     // phase C
+    if (k <= SELECT_FAST_K_MAX && reid_knob(KNOB_TOPK_TILE) != 9)
+        return launch_select_fast(Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt, cap, k, out_idx, out_score, Nq, s);
     const size_t lds = (size_t)cap * 8 + (size_t)D * 4;
     REID_MAX_LDS((select_kernel), 8192 * 8 + 1024 * 4);
     hipLaunchKernelGGL(select_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt, cap, k, out_idx, out_score, Nq);
@@ -764,6 +776,122 @@ __global__ __launch_bounds__(256) void stream_merge_kernel(const float* __restri
         out_idx[(size_t)q * k + lane] = lane < real ? e.i : -1;
         out_score[(size_t)q * k + lane] = lane < real ? e.s : -INFINITY;
     }
+}
+
+// ------------------------------------------------------------------------------------------ phase C, fast form (k <= 32)
+// select_kernel walked ALL candidates of a query (~400 at 200k rows) four at a time, each step a dependent global load of the
+// candidate's index and a wave-uniform branch: ~100 steps of ~1 us = 105 us per call at 128 queries, the largest kernel of a
+// mid-size retrieval and ~0.5 ms of the 10k-query one (rocprofv3, r03).  Here every phase is one parallel sweep:
+//   1. candidate scores -> LDS; every thread keeps the two largest of its share, one wave takes the k-th largest of those 512
+//      values: a lower bound a of the k-th largest candidate score (exact unless three of the top k share a thread);
+//   2. survivors (score >= a - 2 eps: about k + a few) are compacted with one LDS atomic each, their gallery indices fetched
+//      in ONE round of loads;
+//   3. the waves re-score the survivors from the fp32 rows, four rows in flight per wave (dot4_acc order: same bits as everywhere);
+//   4. one wave sorts them by (score desc, index asc).
+// More than SELECT_SV survivors (thousands of exact ties): the query is flagged like a candidate-list overflow (exact fallback).
+constexpr int SELECT_SV = 512;
+
+__global__ __launch_bounds__(256) void select_fast_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int D,
+                                                          const int32_t* __restrict__ exq, const int32_t* __restrict__ exg,
+                                                          const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_score,
+                                                          const int32_t* __restrict__ cand_cnt, int cap, int k,
+                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_score, int Nq) {
+    extern __shared__ __attribute__((aligned(16))) char smf[];
+    float* sc = (float*)smf;                               // [cap] 16-bit-operand scores of the candidates
+    float* qrow = sc + ((cap + 3) & ~3);                   // [D], 16-byte aligned
+    float* t2s = qrow + D;                                 // [512] per-thread top two
+    int32_t* t2i = (int32_t*)(t2s + 512);                  // [512] (positions: distinct keys for the sort)
+    float* svs = (float*)(t2i + 512);                      // [SELECT_SV] survivors: exact scores
+    int32_t* svi = (int32_t*)(svs + SELECT_SV);            // [SELECT_SV] gallery indices
+    int32_t* svc = svi + SELECT_SV;                        // [SELECT_SV] candidate positions
+    __shared__ int nsv;
+    __shared__ float thr2;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cnt = cand_cnt[q];
+    if (cnt > cap) {                                       // overflow: caller takes the exact fallback
+        if (tid == 0) { out_idx[(size_t)q * k] = -2; out_score[(size_t)q * k] = 0.f; }
+        return;
+    }
+    if (tid == 0) nsv = 0;
+    for (int i = tid * 4; i < D; i += 1024) *(f32x4*)(qrow + i) = *(const f32x4*)(Qf + (size_t)q * D + i);
+    const float* cs = cand_score + (size_t)q * cap;
+    float a0 = -INFINITY, a1 = -INFINITY;
+    for (int c = tid; c < cnt; c += 256) {
+        const float v = cs[c];
+        sc[c] = v;
+        const float hi = fmaxf(a0, v);
+        a1 = fmaxf(a1, fminf(a0, v));
+        a0 = hi;
+    }
+    t2s[tid] = a0; t2i[tid] = a0 > -INFINITY ? tid : -1;
+    t2s[256 + tid] = a1; t2i[256 + tid] = a1 > -INFINITY ? 256 + tid : -1;
+    __syncthreads();
+    if (w == 0) {
+        LaneList e;
+        const int real = wave_select_lds(t2s, t2i, 512, k, lane, e);
+        const float kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.s), real > 0 ? real - 1 : 0));
+        if (lane == 0) thr2 = (real < k || cnt < k) ? -INFINITY : kth - 2.f * EPS_BF16;
+    }
+    __syncthreads();
+    const float t2 = thr2;
+    for (int c = tid; c < cnt; c += 256) {
+        if (sc[c] >= t2) {
+            const int pos = atomicAdd(&nsv, 1);
+            if (pos < SELECT_SV) svc[pos] = c;
+        }
+    }
+    __syncthreads();
+    const int n = nsv;
+    if (n > SELECT_SV) {
+        if (tid == 0) { out_idx[(size_t)q * k] = -2; out_score[(size_t)q * k] = 0.f; }
+        return;
+    }
+    for (int i = tid; i < n; i += 256) svi[i] = cand_idx[(size_t)q * cap + svc[i]];
+    __syncthreads();
+    const int eq = exq ? exq[q] : -1;
+    const int nd = D >> 8;                                 // 16-byte pieces per lane (D = 256 nd; D % 64 == 0: a ragged tail below)
+    for (int i0 = w * 4; i0 < n; i0 += 16) {               // four rows in flight per wave
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        int gi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gi[u] = svi[i0 + u < n ? i0 + u : n - 1];
+        for (int j = 0; j <= nd; ++j) {
+            const int i = lane * 4 + j * 256;
+            if (i >= D) break;
+            const f32x4 a = *(const f32x4*)(qrow + i);
+            f32x4 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = *(const f32x4*)(Gf + (size_t)gi[u] * D + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = dot4_acc(s[u], a, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = wave_sum(s[u]);
+            if (eq >= 0 && exg[gi[u]] == eq) v = -1e9f;
+            if (lane == 0 && i0 + u < n) svs[i0 + u] = v;
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    LaneList e;
+    const int real = wave_select_lds(svs, svi, n, k, lane, e);
+    if (lane < k) {
+        out_idx[(size_t)q * k + lane] = lane < real ? e.i : -1;
+        out_score[(size_t)q * k + lane] = lane < real ? e.s : -INFINITY;
+    }
+}
+
+int launch_select_fast(const float* Qf, const float* Gf, int D, const int32_t* exq, const int32_t* exg, const int32_t* cand_idx,
+                       const float* cand_score, const int32_t* cand_cnt, int cap, int k, int32_t* out_idx, float* out_score, int Nq,
+                       hipStream_t s) {
+    const size_t lds = (size_t)((cap + 3) & ~3) * 4 + (size_t)D * 4 + 512 * 8 + (size_t)SELECT_SV * 12;
+    REID_MAX_LDS((select_fast_kernel), 8192 * 4 + 1024 * 4 + 512 * 8 + SELECT_SV * 12);
+    hipLaunchKernelGGL(select_fast_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exq, exg, cand_idx, cand_score, cand_cnt, cap, k, out_idx,
+                       out_score, Nq);
+    REID_CHECK_LAUNCH("reid_cosine_topk(select)");
+    return REID_OK;
 }
 
 }  // namespace

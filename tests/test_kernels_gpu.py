@@ -494,6 +494,36 @@ def test_cosine_topk_matches_fp32_stable_argsort(ops, Nq, Ng, k):
         assert idx[0, :3].tolist() == [3, 5, 100]
 
 
+@pytest.mark.parametrize('Nq,Ng,D,k', [(128, 200000, 512, 10), (37, 50000, 256, 32), (5, 1000, 512, 7), (3, 40, 64, 10)])
+def test_cosine_topk_fast_select_equals_first_form(ops, Nq, Ng, D, k):
+    """Phase C of the batched retrieval in its parallel form (select_fast_kernel: k <= 32) returns the same indices and the same
+    fp32 score bits as the first form (select_kernel, forced with knob TOPK_TILE=9), with planted exact ties, a same-image
+    exclusion and a query that has fewer than k usable rows."""
+    from prcv2025reid_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(Nq * 7 + k)
+    Q = torch.nn.functional.normalize(torch.randn(Nq, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    G[5] = G[3]; G[17] = G[3]; Q[0] = G[3]
+    exq = torch.full((Nq,), -1, device='cuda', dtype=torch.int32); exg = torch.full((Ng,), -1, device='cuda', dtype=torch.int32)
+    exq[1] = 7; exg[torch.randint(0, Ng, (min(50, Ng // 2),), device='cuda', generator=g)] = 7
+    Qb, Gb = ops.to_bf16(Q), ops.to_bf16(G)
+    ws = torch.empty(ops.topk_ws_bytes(Nq, Ng, k), device='cuda', dtype=torch.uint8)
+    res = []
+    try:
+        for knob in (-1, 9):
+            _lib.check(_lib.lib().reid_set_knob(b'TOPK_TILE', knob))
+            idx = torch.full((Nq, k), -7, device='cuda', dtype=torch.int32); sc = torch.zeros(Nq, k, device='cuda')
+            ops.cosine_topk(Qb, Gb, Q, G, k, ws, idx, sc, exclude_q=exq, exclude_g=exg)
+            res.append((idx, sc))
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'TOPK_TILE', -1))
+    assert int((res[0][0][:, 0] == -2).sum()) == 0 and int((res[1][0][:, 0] == -2).sum()) == 0
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))
+    if k >= 3:
+        assert res[0][0][0, :3].tolist() == [3, 5, 17]
+
+
 @pytest.mark.parametrize('Nq,Ng,D,k', [(1, 5000, 512, 10), (3, 20001, 512, 10), (4, 777, 256, 32), (3, 13, 512, 10), (2, 4096, 1024, 1),
                                         (4, 100000, 512, 10)])
 def test_cosine_topk_stream_equals_batched_path(ops, Nq, Ng, D, k):
