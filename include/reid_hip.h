@@ -185,6 +185,16 @@ int reid_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
  * table[e] = {src_off, rows, cols, dst_off, dstT_off} (int64, element offsets; a negative dst offset skips that copy).
  * dst gets the same-layout bf16 copy at dst_off and the TRANSPOSED bf16 copy at dstT_off.  One launch per step. */
 int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table, int32_t n_entries, void* stream);
+/* Adapter gradients of one MERLinear whose output width is N = 768 (autograd of LoRAAdapter, mer_lora.py:40-49), both products that
+ * read the output cotangent dY in ONE pass:
+ *   U[m, :]  = mask_modality(dY[m, :] . B) * scale      (16-bit [M, Rp]; column c kept iff c / mask_r == img_mod[m / rows_per_img];
+ *                                                        BT = B^T [Rp, N] 16-bit; the operand of dA = U^T x, reid_gemm_tn)
+ *   dB      += dY^T . T                                  (fp32 [N, Rp], atomics; T = the forward's masked x . A^T, 16-bit [M, Rp])
+ * Rp must be 32.  Other shapes: reid_mer_gemm (U) + reid_gemm_tn (dB). */
+int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U, int32_t ldu,
+                        float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t N,
+                        int32_t Rp, float scale, void* stream);
+
 /* Merged MER-LoRA weights (mer_lora.py:80-99): for every table entry e and modality mu < nmod
  *     W_eff[e][mu] = W_e + scaling * Bcat_e[:, mu r : (mu+1) r] . Acat_e[g Rp + mu r : g Rp + (mu+1) r, :]      (16-bit, rounded once)
  * and its transpose -- the operands of reid_mer_gemm's row-group form.  table[e] = {W pointer (f32 [N, K] contiguous), arena

@@ -96,7 +96,172 @@ __global__ __launch_bounds__(256) void merge_lora_kernel(const int64_t* __restri
     }
 }
 
+// ---------------------------------------------------------------- adapter gradients of one linear: U = dY.B and dB = dY^T.T in ONE pass over dY
+// r03's side stream read every dY twice: the skinny GEMM U = mask(dY . B) * (alpha/r) (the rank-r cotangent dA = U^T x needs) and the
+// row-reduction dB += dY^T . T.  Leaving the first out takes 1.1 ms off the 32.9 ms step (tools/exp_skip_u.sh: an upper bound), so
+// both products are formed from one staged tile here.  Splitting dY by COLUMN panels (as gemm_tn does) would leave U as N/128 partial
+// sums per row (fp32 atomics: more bytes than the re-read saves); so a workgroup owns a ROW slab and all N = 768 columns: its eight
+// waves own 96 columns each, keep their [96, 32] slice of dB in registers for the whole slab (48 VGPRs) and flush it once, and the
+// eight partial U tiles of a 32-row step are summed through LDS.  N = 3072 (fc1: 393 KB of accumulators, 3/4 of a CU's register
+// file) stays on the two-launch path.
+namespace fused {
+constexpr int N = 768, RP = 32, R = 32;                  // columns of dY, adapter columns, rows per step
+constexpr int CPW = N / 8, MT = CPW / 16, KS = CPW / 32;  // per wave: 96 columns = 6 MFMA row tiles of dB = 3 k-steps of U
+constexpr int XP = CPW * 2 + 32, TP = RP * 2 + 32;        // LDS row pitches (bytes): padded for the transpose reads (gemm_tn.hip)
+constexpr int WAVE_LDS = R * XP + R * TP;
+constexpr int LDS_BYTES = 8 * WAVE_LDS + 8 * R * RP * 4;
+
+typedef __attribute__((ext_vector_type(4))) short s4;
+typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+struct Params {
+    const bf16_t* dY; const bf16_t* T; const bf16_t* BT; bf16_t* U; float* dB;
+    const int32_t* img_mod;
+    int lddy, ldt, ldbt, ldu, lddb, rows_per_img, mask_r, M, slab_rows;
+    float scale;
+};
+
+// gemm_tn.hip's transposed fragment: 16x16x32 operand whose 16 MFMA rows are image COLUMNS col0.. and whose k are image rows k0..k0+31
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int k0, int col0, int lane) {
+    const int l16 = lane & 15, fq = lane >> 4;
+    const int q = l16 >> 2, pp = l16 & 3;
+    const char* a0 = img + (k0 + 4 * fq + q) * pitch + (col0 + 4 * pp) * 2;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a0));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a0 + 16 * pitch));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+#ifndef REID_FUSED_MIN_WAVES
+#define REID_FUSED_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kernel(const Params p) {
+    REID_T16_ENTER();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, fq = lane >> 4;
+    char* xs = smem + w * WAVE_LDS;                       // this wave's [32 rows][96 columns] of dY
+    char* ts = xs + R * XP;                               // its copy of T[32 rows][32]
+    float* ured = (float*)(smem + 8 * WAVE_LDS);          // [8 waves][32 rows][32 columns] partial U
+    const int col0 = w * CPW;
+    const int mbeg = blockIdx.x * p.slab_rows;
+    const int mend = min(p.M, mbeg + p.slab_rows);
+    if (mbeg >= mend) return;                             // (whole workgroup)
+    const int steps = (mend - mbeg + R - 1) / R;
+    // B^T fragments of this wave's columns (B operand of U = dY . B: n = adapter column, k = dY column): constant over the slab
+    bf16x8 bfr[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[ks][j] = *(const bf16x8*)(p.BT + (size_t)(j * 16 + l16) * p.ldbt + col0 + ks * 32 + 8 * fq);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+    uint4 xr[6], tr[2];
+    auto gload = [&](int t) {
+        const int mb = mbeg + t * R;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                     // 32 rows x 12 chunks of 16 bytes
+            const int c = lane + 64 * i, row = c / 12, ch = c % 12;
+            const int m = mb + row;
+            xr[i] = m < mend ? *(const uint4*)(p.dY + (size_t)m * p.lddy + col0 + ch * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                     // 32 rows x 4 chunks
+            const int c = lane + 64 * i, row = c >> 2, ch = c & 3;
+            const int m = mb + row;
+            tr[i] = m < mend ? *(const uint4*)(p.T + (size_t)m * p.ldt + ch * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    gload(0);
+    // (r03, measured and not kept: two steps of operands in flight + alternating partial-U sets for one barrier per step --
+    //  226 VGPRs and 144 KB of LDS leave the CU no room for the main stream's LayerNorm waves: 32.9 instead of 32.55 ms per step)
+    for (int t = 0; t < steps; ++t) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const int c = lane + 64 * i; *(uint4*)(xs + (c / 12) * XP + (c % 12) * 16) = xr[i]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *(uint4*)(ts + (c >> 2) * TP + (c & 3) * 16) = tr[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t + 1 < steps) gload(t + 1);
+        // dB[96 columns of dY, 32] += dY^T . T over the 32 rows of this step
+        const bf16x8 tf0 = tr_frag(ts, TP, 0, 0, lane), tf1 = tr_frag(ts, TP, 0, 16, lane);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bf16x8 xf = tr_frag(xs, XP, 0, i * 16, lane);
+            acc[i][0] = mfma16(xf, tf0, acc[i][0]);
+            acc[i][1] = mfma16(xf, tf1, acc[i][1]);
+        }
+        // partial U[32 rows, 32] over this wave's 96 columns
+        f32x4 ua[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { ua[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ua[mt][1] = ua[mt][0]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bf16x8 af = *(const bf16x8*)(xs + (mt * 16 + l16) * XP + (ks * 32 + 8 * fq) * 2);
+                ua[mt][0] = mfma16(af, bfr[ks][0], ua[mt][0]);
+                ua[mt][1] = mfma16(af, bfr[ks][1], ua[mt][1]);
+            }
+        float* ur = ured + w * (R * RP);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ur[(mt * 16 + 4 * fq + e) * RP + j * 16 + l16] = ua[mt][j][e];
+        __syncthreads();
+        {
+            const int o = tid * 2, row = o >> 5, col = o & 31;
+            const int m = mbeg + t * R + row;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) { const f32x2v u2 = *(const f32x2v*)(ured + ww * (R * RP) + o); v0 += u2[0]; v1 += u2[1]; }
+            if (m < mend) {
+                const int modality = p.img_mod[m / p.rows_per_img];
+                v0 = (col / p.mask_r == modality) ? v0 * p.scale : 0.f;
+                v1 = ((col + 1) / p.mask_r == modality) ? v1 * p.scale : 0.f;
+                *(uint32_t*)(p.U + (size_t)m * p.ldu + col) = pack_bf16x2(v0, v1);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(p.dB + (size_t)(col0 + i * 16 + 4 * fq + e) * p.lddb + j * 16 + l16, acc[i][j][e]);
+}
+}  // namespace fused
+
 }  // namespace
+
+extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U,
+                                   int32_t ldu, float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r,
+                                   int32_t M, int32_t N, int32_t Rp, float scale, void* stream) {
+    REID_CHECK_ARG(dY && T && BT && U && dB && img_mod, "reid_lora_bwd_fused: null pointer");
+    REID_CHECK_ARG(N == fused::N && Rp == fused::RP, "reid_lora_bwd_fused: N=%d Rp=%d (this kernel is built for N = 768, Rp = 32)", N, Rp);
+    REID_CHECK_ARG(M > 0 && rows_per_img > 0 && mask_r > 0 && mask_r <= Rp, "reid_lora_bwd_fused: M=%d rows_per_img=%d mask_r=%d", M, rows_per_img, mask_r);
+    REID_CHECK_ARG(lddy % 8 == 0 && ldt % 8 == 0 && ldbt % 8 == 0 && ldu % 2 == 0 && lddy >= N && ldt >= Rp && ldbt >= N && ldu >= Rp && lddb >= Rp,
+                   "reid_lora_bwd_fused: leading dimensions");
+    REID_CHECK_ARG(((uintptr_t)dY | (uintptr_t)T | (uintptr_t)BT) % 16 == 0 && (uintptr_t)U % 4 == 0, "reid_lora_bwd_fused: operand alignment");
+    fused::Params p{(const bf16_t*)dY, (const bf16_t*)T, (const bf16_t*)BT, (bf16_t*)U, dB, img_mod, lddy, ldt, ldbt, ldu, lddb, rows_per_img,
+                    mask_r, M, 0, scale};
+    // few, long slabs: each workgroup flushes its [768, 32] slice of dB with atomics once (64 slabs = the flush traffic of gemm_tn's grid)
+    int slabs = reid_knob(KNOB_TN_BLOCKS) > 0 ? reid_knob(KNOB_TN_BLOCKS) / 6 : 64;
+    if (slabs < 1) slabs = 1;
+    p.slab_rows = ((M + slabs - 1) / slabs + fused::R - 1) / fused::R * fused::R;
+    slabs = (M + p.slab_rows - 1) / p.slab_rows;
+    REID_MAX_LDS((fused::lora_bwd_fused_kernel), fused::LDS_BYTES);
+    hipLaunchKernelGGL(fused::lora_bwd_fused_kernel, dim3(slabs), dim3(512), fused::LDS_BYTES, (hipStream_t)stream, p);
+    REID_CHECK_LAUNCH("reid_lora_bwd_fused");
+    return REID_OK;
+}
 
 extern "C" int reid_merge_lora_table(const int64_t* table, int32_t n_entries, int32_t max_tiles, const float* arena, void* weff,
                                      int32_t Rp, int32_t r, int32_t nmod, float scaling, void* stream) {

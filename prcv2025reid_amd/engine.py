@@ -38,6 +38,9 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+_EXP_SKIP_U = os.environ.get('REID_EXP_SKIP_U', '0') == '1'
+
+
 class LoraLayout:
     """Where each (layer, linear) adapter set lives in the flat fp32 arena and in the bf16 pack arena."""
 
@@ -543,21 +546,30 @@ class Engine:
             if cur_dxb is not dxb:
                 cur_dxb.copy_(dxb)
 
+        fuse_u_db = os.environ.get('REID_LORA_FUSED', '1') != '0'
+
         def lora_grads(l, calls):
             """Adapter gradients of one linear on the side stream: U = mask(dY . Bcat) * (alpha/r), dB += dY^T T, dA += U^T X.
             ``calls`` = [(dY, BT, U, mask kwargs, [(X operand, Y operand, out), ...])]."""
-            if side is None:
+            def run():
                 for dY, BT, U, kw, tns in calls:
-                    ops.gemm(dY, BT, U, **kw)
-                    for xx, yy, out in tns:
+                    # tns[0] = (dY, T, dB): with N = 768 output columns (every linear but fc1) U and dB come out of ONE pass over dY
+                    same = tns[0][0].data_ptr() == dY.data_ptr() and tns[0][0].shape == dY.shape and tns[0][0].stride() == dY.stride()
+                    if fuse_u_db and same and ops.lora_bwd_fused_ok(dY.shape[1], tns[0][1].shape[1]):
+                        ops.lora_bwd_fused(dY, tns[0][1], BT, U, tns[0][2], kw['img_mod'], kw['rows_per_img'], kw['mask_r'], kw['alpha'])
+                        rest = tns[1:]
+                    else:
+                        if not _EXP_SKIP_U:                  # (timing experiment only: REID_EXP_SKIP_U=1 leaves U unwritten -> wrong dA)
+                            ops.gemm(dY, BT, U, **kw)
+                        rest = tns
+                    for xx, yy, out in rest:
                         ops.gemm_tn(xx, yy, out, beta=1.0)
+            if side is None:
+                run()
                 return
             ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
             with torch.cuda.stream(side):
-                for dY, BT, U, kw, tns in calls:
-                    ops.gemm(dY, BT, U, **kw)
-                    for xx, yy, out in tns:
-                        ops.gemm_tn(xx, yy, out, beta=1.0)
+                run()
 
         def layer_done(l):
             if side is not None:

@@ -179,6 +179,17 @@ def cast_bf16_f32(src, dst):
     return dst
 
 
+def lora_bwd_fused(dY, T, BT, U, dB, img_mod, rows_per_img, mask_r, scale):
+    """U = mask(dY . B) * scale and dB += dY^T . T from one pass over dY (N = 768, Rp = 32); see reid_lora_bwd_fused."""
+    check(lib().reid_lora_bwd_fused(ptr(dY), dY.stride(0), ptr(T), T.stride(0), ptr(BT), BT.stride(0), ptr(U), U.stride(0), ptr(dB),
+                                    dB.stride(0), ptr(img_mod), rows_per_img, mask_r, dY.shape[0], dY.shape[1], T.shape[1],
+                                    C.c_float(scale), stream_ptr()))
+
+
+def lora_bwd_fused_ok(N, Rp):
+    return N == 768 and Rp == 32
+
+
 def merge_lora_table(table, n_entries, max_tiles, arena, weff, Rp, r, nmod, scaling):
     check(lib().reid_merge_lora_table(ptr(table), n_entries, max_tiles, ptr(arena), ptr(weff), Rp, r, nmod, C.c_float(scaling), stream_ptr()))
 

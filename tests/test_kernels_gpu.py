@@ -494,6 +494,37 @@ def test_cosine_topk_matches_fp32_stable_argsort(ops, Nq, Ng, k):
         assert idx[0, :3].tolist() == [3, 5, 100]
 
 
+@pytest.mark.parametrize('n_img,rpi,r,lddy_extra', [(24, 197, 8, 0), (7, 197, 4, 1536), (256, 1, 8, 0), (3, 50, 8, 768)])
+def test_lora_bwd_fused_equals_two_launch_path(ops, n_img, rpi, r, lddy_extra):
+    """reid_lora_bwd_fused (U = mask(dY.B) * s and dB += dY^T.T from one pass over dY) against the two launches it replaces
+    (reid_mer_gemm with the modality mask + reid_gemm_tn) and against fp64: ragged last row step, dY as a column block of a wider
+    matrix (the q|k|v cotangent), class-row form (one row per image), accumulation into a non-zero dB."""
+    M, N, Rp = n_img * rpi, 768, 32
+    g = torch.Generator(device='cuda').manual_seed(M + r)
+    wide = torch.randn(M, N + lddy_extra, device='cuda', generator=g)
+    dYw = bf(wide); dY = dYw[:, lddy_extra // 2: lddy_extra // 2 + N] if lddy_extra else dYw
+    mods = torch.randint(0, 4, (n_img,), device='cuda', generator=g).to(torch.int32)
+    Tm = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3)
+    B = torch.randn(N, Rp, device='cuda', generator=g) * 0.1
+    BT = bf(B.t().contiguous())
+    scale = 32.0 / r
+    dB0 = torch.randn(N, Rp, device='cuda', generator=g)
+    # the two-launch path
+    U_ref = torch.empty(M, Rp, device='cuda', dtype=T16()); dB_ref = dB0.clone()
+    ops.gemm(dY, BT, U_ref, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=scale)
+    ops.gemm_tn(dY, Tm, dB_ref, beta=1.0)
+    U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = dB0.clone()
+    ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale)
+    # fp64
+    row_mod = mods.long().repeat_interleave(rpi)
+    keep = (torch.arange(Rp, device='cuda').view(1, -1) // r) == row_mod.view(-1, 1)
+    U64 = (dY.double() @ BT.double().t()) * scale * keep
+    dB64 = dB0.double() + dY.double().t() @ Tm.double()
+    assert rel_err(U.float(), U64.float()) < 6e-3 and rel_err(dB, dB64.float()) < 1e-5
+    assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5
+    assert float(U.float()[~keep].abs().max()) == 0.0                      # other modalities' columns are exactly zero
+
+
 @pytest.mark.parametrize('Nq,Ng,D,k', [(128, 200000, 512, 10), (37, 50000, 256, 32), (5, 1000, 512, 7), (3, 40, 64, 10)])
 def test_cosine_topk_fast_select_equals_first_form(ops, Nq, Ng, D, k):
     """Phase C of the batched retrieval in its parallel form (select_fast_kernel: k <= 32) returns the same indices and the same
