@@ -190,10 +190,13 @@ int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table,
  *   U[m, :]  = mask_modality(dY[m, :] . B) * scale      (16-bit [M, Rp]; column c kept iff c / mask_r == img_mod[m / rows_per_img];
  *                                                        BT = B^T [Rp, N] 16-bit; the operand of dA = U^T x, reid_gemm_tn)
  *   dB      += dY^T . T                                  (fp32 [N, Rp], atomics; T = the forward's masked x . A^T, 16-bit [M, Rp])
- * Rp must be 32.  Other shapes: reid_mer_gemm (U) + reid_gemm_tn (dB). */
+ * Rp must be 32.  A wider cotangent (fc1: 3072 columns) is handled as column blocks of 768, one launch each on the same stream:
+ * u_mode bit 0 = add the fp32 partial sums u_partial [M, 32] of the earlier blocks to this block's, bit 1 = store the sum to
+ * u_partial instead of finishing U (mask, scale, 16-bit); the last block has bit 1 clear.  u_mode = 0: a 768-column linear, u_partial unused.
+ * Other shapes: reid_mer_gemm (U) + reid_gemm_tn (dB). */
 int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U, int32_t ldu,
                         float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t N,
-                        int32_t Rp, float scale, void* stream);
+                        int32_t Rp, float scale, float* u_partial, int32_t u_mode, void* stream);
 
 /* Merged MER-LoRA weights (mer_lora.py:80-99): for every table entry e and modality mu < nmod
  *     W_eff[e][mu] = W_e + scaling * Bcat_e[:, mu r : (mu+1) r] . Acat_e[g Rp + mu r : g Rp + (mu+1) r, :]      (16-bit, rounded once)

@@ -120,6 +120,8 @@ struct Params {
     const int32_t* img_mod;
     int lddy, ldt, ldbt, ldu, lddb, rows_per_img, mask_r, M, slab_rows;
     float scale;
+    float* Up;                                            // fp32 [M, 32] partial sums of U over column blocks of a wider dY (or null)
+    int u_mode;                                           // bit 0: add Up to this block's sum; bit 1: store the sum to Up instead of U
 };
 
 // gemm_tn.hip's transposed fragment: 16x16x32 operand whose 16 MFMA rows are image COLUMNS col0.. and whose k are image rows k0..k0+31
@@ -220,7 +222,13 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) { const f32x2v u2 = *(const f32x2v*)(ured + ww * (R * RP) + o); v0 += u2[0]; v1 += u2[1]; }
-            if (m < mend) {
+            if (m < mend && (p.u_mode & 1)) {              // earlier column blocks of the same rows (launches of one stream: no atomics)
+                const f32x2v u2 = *(const f32x2v*)(p.Up + (size_t)m * RP + col);
+                v0 += u2[0]; v1 += u2[1];
+            }
+            if (m < mend && (p.u_mode & 2)) {
+                *(f32x2v*)(p.Up + (size_t)m * RP + col) = f32x2v{v0, v1};
+            } else if (m < mend) {
                 const int modality = p.img_mod[m / p.rows_per_img];
                 v0 = (col / p.mask_r == modality) ? v0 * p.scale : 0.f;
                 v1 = ((col + 1) / p.mask_r == modality) ? v1 * p.scale : 0.f;
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
 
 extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U,
                                    int32_t ldu, float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r,
-                                   int32_t M, int32_t N, int32_t Rp, float scale, void* stream) {
+                                   int32_t M, int32_t N, int32_t Rp, float scale, float* u_partial, int32_t u_mode, void* stream) {
+    REID_CHECK_ARG(u_mode >= 0 && u_mode <= 3 && (u_mode == 0 || u_partial), "reid_lora_bwd_fused: u_mode=%d needs u_partial", u_mode);
     REID_CHECK_ARG(dY && T && BT && U && dB && img_mod, "reid_lora_bwd_fused: null pointer");
     REID_CHECK_ARG(N == fused::N && Rp == fused::RP, "reid_lora_bwd_fused: N=%d Rp=%d (this kernel is built for N = 768, Rp = 32)", N, Rp);
     REID_CHECK_ARG(M > 0 && rows_per_img > 0 && mask_r > 0 && mask_r <= Rp, "reid_lora_bwd_fused: M=%d rows_per_img=%d mask_r=%d", M, rows_per_img, mask_r);
@@ -251,7 +260,7 @@ extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, 
                    "reid_lora_bwd_fused: leading dimensions");
     REID_CHECK_ARG(((uintptr_t)dY | (uintptr_t)T | (uintptr_t)BT) % 16 == 0 && (uintptr_t)U % 4 == 0, "reid_lora_bwd_fused: operand alignment");
     fused::Params p{(const bf16_t*)dY, (const bf16_t*)T, (const bf16_t*)BT, (bf16_t*)U, dB, img_mod, lddy, ldt, ldbt, ldu, lddb, rows_per_img,
-                    mask_r, M, 0, scale};
+                    mask_r, M, 0, scale, u_partial, u_mode};
     // few, long slabs: each workgroup flushes its [768, 32] slice of dB with atomics once (64 slabs = the flush traffic of gemm_tn's grid)
     int slabs = reid_knob(KNOB_TN_BLOCKS) > 0 ? reid_knob(KNOB_TN_BLOCKS) / 6 : 64;
     if (slabs < 1) slabs = 1;

@@ -547,6 +547,8 @@ class Engine:
                 cur_dxb.copy_(dxb)
 
         fuse_u_db = os.environ.get('REID_LORA_FUSED', '1') != '0'
+        fuse_max_n = 768 if os.environ.get('REID_LORA_FUSED') == '768' else 1 << 30      # (A/B: only the 768-column linears)
+        u_part = torch.empty(M, Rp, **f32) if fuse_u_db else None      # fp32 partial U of fc1's four column blocks (side stream only)
 
         def lora_grads(l, calls):
             """Adapter gradients of one linear on the side stream: U = mask(dY . Bcat) * (alpha/r), dB += dY^T T, dA += U^T X.
@@ -555,8 +557,9 @@ class Engine:
                 for dY, BT, U, kw, tns in calls:
                     # tns[0] = (dY, T, dB): with N = 768 output columns (every linear but fc1) U and dB come out of ONE pass over dY
                     same = tns[0][0].data_ptr() == dY.data_ptr() and tns[0][0].shape == dY.shape and tns[0][0].stride() == dY.stride()
-                    if fuse_u_db and same and ops.lora_bwd_fused_ok(dY.shape[1], tns[0][1].shape[1]):
-                        ops.lora_bwd_fused(dY, tns[0][1], BT, U, tns[0][2], kw['img_mod'], kw['rows_per_img'], kw['mask_r'], kw['alpha'])
+                    if fuse_u_db and same and ops.lora_bwd_fused_ok(dY.shape[1], tns[0][1].shape[1]) and dY.shape[1] <= fuse_max_n:
+                        ops.lora_bwd_fused(dY, tns[0][1], BT, U, tns[0][2], kw['img_mod'], kw['rows_per_img'], kw['mask_r'], kw['alpha'],
+                                           u_partial=u_part[:dY.shape[0]] if dY.shape[1] > 768 else None)
                         rest = tns[1:]
                     else:
                         if not _EXP_SKIP_U:                  # (timing experiment only: REID_EXP_SKIP_U=1 leaves U unwritten -> wrong dA)

@@ -179,15 +179,23 @@ def cast_bf16_f32(src, dst):
     return dst
 
 
-def lora_bwd_fused(dY, T, BT, U, dB, img_mod, rows_per_img, mask_r, scale):
-    """U = mask(dY . B) * scale and dB += dY^T . T from one pass over dY (N = 768, Rp = 32); see reid_lora_bwd_fused."""
-    check(lib().reid_lora_bwd_fused(ptr(dY), dY.stride(0), ptr(T), T.stride(0), ptr(BT), BT.stride(0), ptr(U), U.stride(0), ptr(dB),
-                                    dB.stride(0), ptr(img_mod), rows_per_img, mask_r, dY.shape[0], dY.shape[1], T.shape[1],
-                                    C.c_float(scale), stream_ptr()))
+def lora_bwd_fused(dY, T, BT, U, dB, img_mod, rows_per_img, mask_r, scale, u_partial=None):
+    """U = mask(dY . B) * scale and dB += dY^T . T from one pass over dY (Rp = 32; N = 768, or a multiple of 768 as column blocks with
+    the fp32 scratch ``u_partial`` [M, 32]); see reid_lora_bwd_fused."""
+    N = dY.shape[1]
+    nb = N // 768
+    if nb > 1 and u_partial is None:
+        raise ValueError('lora_bwd_fused: a cotangent wider than 768 columns needs u_partial')
+    for q in range(nb):
+        mode = 0 if nb == 1 else ((1 if q > 0 else 0) | (2 if q + 1 < nb else 0))
+        dYq, BTq, dBq = dY[:, q * 768:(q + 1) * 768], BT[:, q * 768:(q + 1) * 768], dB[q * 768:(q + 1) * 768]
+        check(lib().reid_lora_bwd_fused(ptr(dYq), dYq.stride(0), ptr(T), T.stride(0), ptr(BTq), BTq.stride(0), ptr(U), U.stride(0),
+                                        ptr(dBq), dBq.stride(0), ptr(img_mod), rows_per_img, mask_r, dY.shape[0], 768, T.shape[1],
+                                        C.c_float(scale), ptr(u_partial), mode, stream_ptr()))
 
 
 def lora_bwd_fused_ok(N, Rp):
-    return N == 768 and Rp == 32
+    return N % 768 == 0 and N // 768 in (1, 2, 3, 4) and Rp == 32
 
 
 def merge_lora_table(table, n_entries, max_tiles, arena, weff, Rp, r, nmod, scaling):

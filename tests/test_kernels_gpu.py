@@ -525,6 +525,27 @@ def test_lora_bwd_fused_equals_two_launch_path(ops, n_img, rpi, r, lddy_extra):
     assert float(U.float()[~keep].abs().max()) == 0.0                      # other modalities' columns are exactly zero
 
 
+def test_lora_bwd_fused_wide_cotangent_as_column_blocks(ops):
+    """fc1's cotangent has 3072 columns: four launches over 768-column blocks, U summed through the fp32 scratch, equal the two-launch
+    path on the whole matrix."""
+    n_img, rpi, r, N, Rp = 5, 197, 8, 3072, 32
+    M = n_img * rpi
+    g = torch.Generator(device='cuda').manual_seed(11)
+    dY = bf(torch.randn(M, N, device='cuda', generator=g))
+    mods = torch.randint(0, 4, (n_img,), device='cuda', generator=g).to(torch.int32)
+    Tm = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3)
+    BT = bf((torch.randn(N, Rp, device='cuda', generator=g) * 0.05).t().contiguous())
+    scale = 4.0
+    U_ref = torch.empty(M, Rp, device='cuda', dtype=T16()); dB_ref = torch.zeros(N, Rp, device='cuda')
+    ops.gemm(dY, BT, U_ref, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=scale)
+    ops.gemm_tn(dY, Tm, dB_ref, beta=1.0)
+    U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = torch.zeros(N, Rp, device='cuda')
+    scratch = torch.full((M, Rp), float('nan'), device='cuda')            # never read before it is written
+    ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale, u_partial=scratch)
+    assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5
+    assert bool(torch.isfinite(U.float()).all())
+
+
 @pytest.mark.parametrize('Nq,Ng,D,k', [(128, 200000, 512, 10), (37, 50000, 256, 32), (5, 1000, 512, 7), (3, 40, 64, 10)])
 def test_cosine_topk_fast_select_equals_first_form(ops, Nq, Ng, D, k):
     """Phase C of the batched retrieval in its parallel form (select_fast_kernel: k <= 32) returns the same indices and the same
