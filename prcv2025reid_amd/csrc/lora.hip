@@ -106,10 +106,17 @@ __global__ __launch_bounds__(256) void merge_lora_kernel(const int64_t* __restri
 // file) stays on the two-launch path.
 namespace fused {
 constexpr int N = 768, RP = 32, R = 32;                  // columns of dY, adapter columns, rows per step
-constexpr int CPW = N / 8, MT = CPW / 16, KS = CPW / 32;  // per wave: 96 columns = 6 MFMA row tiles of dB = 3 k-steps of U
-constexpr int XP = CPW * 2 + 32, TP = RP * 2 + 32;        // LDS row pitches (bytes): padded for the transpose reads (gemm_tn.hip)
-constexpr int WAVE_LDS = R * XP + R * TP;
-constexpr int LDS_BYTES = 8 * WAVE_LDS + 8 * R * RP * 4;
+constexpr int TP = RP * 2 + 32;                           // LDS row pitch of the T tile (bytes): padded for the transpose reads (gemm_tn.hip)
+// NW waves per workgroup, each owning N / NW columns.  NW = 8 (96 columns, 113 KB of LDS: one workgroup per CU) is what runs: every
+// 32-row step is one exposed HBM round trip (~4.5 us in the train step = 14 GB/s per CU).  NW = 4 (192 columns, 80 KB: TWO workgroups
+// per CU, each waiting for its own loads) compiles to 256 VGPRs + 40 spilled (96 accumulator + 48 B^T-fragment + 56 staging registers):
+// not instantiated; the staging registers would have to go (LDS-DMA) first.
+template <int NW> struct Geo {
+    static constexpr int CPW = N / NW, MT = CPW / 16, KS = CPW / 32, CH = CPW / 8, XL = R * CH / 64;
+    static constexpr int XP = CPW * 2 + 32;
+    static constexpr int WAVE_LDS = R * XP + R * TP;
+    static constexpr int LDS_BYTES = NW * WAVE_LDS + NW * R * RP * 4;
+};
 
 typedef __attribute__((ext_vector_type(4))) short s4;
 typedef __attribute__((address_space(3))) s4* lds_s4_ptr;
@@ -134,18 +141,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int k0, in
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-#ifndef REID_FUSED_MIN_WAVES
-#define REID_FUSED_MIN_WAVES 2
-#endif
-__global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kernel(const Params p) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void lora_bwd_fused_kernel(const Params p) {
     REID_T16_ENTER();
+    using G = Geo<NW>;
+    constexpr int CPW = G::CPW, MT = G::MT, KS = G::KS, CH = G::CH, XL = G::XL, XP = G::XP, WAVE_LDS = G::WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, fq = lane >> 4;
-    char* xs = smem + w * WAVE_LDS;                       // this wave's [32 rows][96 columns] of dY
+    char* xs = smem + w * WAVE_LDS;                       // this wave's [32 rows][CPW columns] of dY
     char* ts = xs + R * XP;                               // its copy of T[32 rows][32]
-    float* ured = (float*)(smem + 8 * WAVE_LDS);          // [8 waves][32 rows][32 columns] partial U
+    float* ured = (float*)(smem + NW * WAVE_LDS);         // [NW waves][32 rows][32 columns] partial U
     const int col0 = w * CPW;
     const int mbeg = blockIdx.x * p.slab_rows;
     const int mend = min(p.M, mbeg + p.slab_rows);
@@ -160,12 +167,12 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
     f32x4 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-    uint4 xr[6], tr[2];
+    uint4 xr[XL], tr[2];
     auto gload = [&](int t) {
         const int mb = mbeg + t * R;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {                     // 32 rows x 12 chunks of 16 bytes
-            const int c = lane + 64 * i, row = c / 12, ch = c % 12;
+        for (int i = 0; i < XL; ++i) {                    // 32 rows x CH chunks of 16 bytes
+            const int c = lane + 64 * i, row = c / CH, ch = c % CH;
             const int m = mb + row;
             xr[i] = m < mend ? *(const uint4*)(p.dY + (size_t)m * p.lddy + col0 + ch * 8) : uint4{0u, 0u, 0u, 0u};
         }
@@ -181,14 +188,14 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
     //  226 VGPRs and 144 KB of LDS leave the CU no room for the main stream's LayerNorm waves: 32.9 instead of 32.55 ms per step)
     for (int t = 0; t < steps; ++t) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { const int c = lane + 64 * i; *(uint4*)(xs + (c / 12) * XP + (c % 12) * 16) = xr[i]; }
+        for (int i = 0; i < XL; ++i) { const int c = lane + 64 * i; *(uint4*)(xs + (c / CH) * XP + (c % CH) * 16) = xr[i]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *(uint4*)(ts + (c >> 2) * TP + (c & 3) * 16) = tr[i]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (t + 1 < steps) gload(t + 1);
-        // dB[96 columns of dY, 32] += dY^T . T over the 32 rows of this step
+        // dB[CPW columns of dY, 32] += dY^T . T over the 32 rows of this step
         const bf16x8 tf0 = tr_frag(ts, TP, 0, 0, lane), tf1 = tr_frag(ts, TP, 0, 16, lane);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
             acc[i][0] = mfma16(xf, tf0, acc[i][0]);
             acc[i][1] = mfma16(xf, tf1, acc[i][1]);
         }
-        // partial U[32 rows, 32] over this wave's 96 columns
+        // partial U[32 rows, 32] over this wave's columns
         f32x4 ua[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) { ua[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ua[mt][1] = ua[mt][0]; }
@@ -216,12 +223,13 @@ __global__ __launch_bounds__(512, REID_FUSED_MIN_WAVES) void lora_bwd_fused_kern
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ur[(mt * 16 + 4 * fq + e) * RP + j * 16 + l16] = ua[mt][j][e];
         __syncthreads();
-        {
-            const int o = tid * 2, row = o >> 5, col = o & 31;
+#pragma unroll
+        for (int o = tid * 2; o < R * RP; o += NW * 128) {
+            const int row = o >> 5, col = o & 31;
             const int m = mbeg + t * R + row;
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) { const f32x2v u2 = *(const f32x2v*)(ured + ww * (R * RP) + o); v0 += u2[0]; v1 += u2[1]; }
+            for (int ww = 0; ww < NW; ++ww) { const f32x2v u2 = *(const f32x2v*)(ured + ww * (R * RP) + o); v0 += u2[0]; v1 += u2[1]; }
             if (m < mend && (p.u_mode & 1)) {              // earlier column blocks of the same rows (launches of one stream: no atomics)
                 const f32x2v u2 = *(const f32x2v*)(p.Up + (size_t)m * RP + col);
                 v0 += u2[0]; v1 += u2[1];
@@ -266,8 +274,8 @@ extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, 
     if (slabs < 1) slabs = 1;
     p.slab_rows = ((M + slabs - 1) / slabs + fused::R - 1) / fused::R * fused::R;
     slabs = (M + p.slab_rows - 1) / p.slab_rows;
-    REID_MAX_LDS((fused::lora_bwd_fused_kernel), fused::LDS_BYTES);
-    hipLaunchKernelGGL(fused::lora_bwd_fused_kernel, dim3(slabs), dim3(512), fused::LDS_BYTES, (hipStream_t)stream, p);
+    REID_MAX_LDS((fused::lora_bwd_fused_kernel<8>), fused::Geo<8>::LDS_BYTES);
+    hipLaunchKernelGGL(fused::lora_bwd_fused_kernel<8>, dim3(slabs), dim3(512), fused::Geo<8>::LDS_BYTES, (hipStream_t)stream, p);
     REID_CHECK_LAUNCH("reid_lora_bwd_fused");
     return REID_OK;
 }
