@@ -1,0 +1,11 @@
+#!/bin/bash
+# row slabs of the fused adapter-gradient kernel (REID_TN_BLOCKS / 6 slabs; default 64): duration vs CU-time on the side stream
+run() {
+  env "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-retrieval --no-parity --no-second-flavor 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
+print('  value', round(d['value'], 1), 'ms', round(d['ms_per_step'], 2), 'gemm frac', round(r['frac'], 4), 'gemm ms/step', round(r['kernel_ms_per_step'], 2))"
+}
+for spec in "X=0" "REID_TN_BLOCKS=576" "REID_TN_BLOCKS=768" "REID_TN_BLOCKS=1152" "X=0" "REID_TN_BLOCKS=288"; do
+  echo "$spec"; run $spec
+done
