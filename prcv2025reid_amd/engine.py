@@ -39,6 +39,7 @@ def round_up(a, b):
 
 
 _EXP_SKIP_U = os.environ.get('REID_EXP_SKIP_U', '0') == '1'
+_EXP_SKIP_DA = os.environ.get('REID_EXP_SKIP_DA', '0') == '1'
 
 
 class LoraLayout:
@@ -566,7 +567,8 @@ class Engine:
                             ops.gemm(dY, BT, U, **kw)
                         rest = tns
                     for xx, yy, out in rest:
-                        ops.gemm_tn(xx, yy, out, beta=1.0)
+                        if not _EXP_SKIP_DA:                 # (timing experiment only: REID_EXP_SKIP_DA=1 leaves dA unwritten)
+                            ops.gemm_tn(xx, yy, out, beta=1.0)
             if side is None:
                 run()
                 return
