@@ -13,6 +13,7 @@
 // smaller than one ulp of W moves a fraction |delta| / ulp of the rounded elements by one ulp: unbiased, like the fp32-master /
 // 16-bit-compute weights of ordinary mixed-precision training.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -167,34 +168,41 @@ __global__ __launch_bounds__(NW * 64, 2) void lora_bwd_fused_kernel(const Params
     f32x4 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-    uint4 xr[XL], tr[2];
-    auto gload = [&](int t) {
+#ifndef REID_FUSED_DEPTH
+#define REID_FUSED_DEPTH 1
+#endif
+    // DEPTH steps of operands in flight in registers (1 or 2).  The slot of a step is a compile-time constant (the loop is unrolled by
+    // DEPTH): indexing the register arrays with (t & 1) put them into scratch memory (80 bytes per lane: 35.0 ms per step).  Two steps
+    // in flight (226 VGPRs) change nothing: 32.61 / 32.73 against 32.88 / 32.71 ms per step on one box (profiles/r03_lora_fused_depth.log)
+    // -- the step is not what waits for HBM; one step in flight (194 VGPRs) stays.
+    constexpr int DEPTH = REID_FUSED_DEPTH;
+    uint4 xr[DEPTH][XL], tr[DEPTH][2];
+    auto gload = [&](int t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
         const int mb = mbeg + t * R;
 #pragma unroll
         for (int i = 0; i < XL; ++i) {                    // 32 rows x CH chunks of 16 bytes
             const int c = lane + 64 * i, row = c / CH, ch = c % CH;
             const int m = mb + row;
-            xr[i] = m < mend ? *(const uint4*)(p.dY + (size_t)m * p.lddy + col0 + ch * 8) : uint4{0u, 0u, 0u, 0u};
+            xr[slot][i] = m < mend ? *(const uint4*)(p.dY + (size_t)m * p.lddy + col0 + ch * 8) : uint4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                     // 32 rows x 4 chunks
             const int c = lane + 64 * i, row = c >> 2, ch = c & 3;
             const int m = mb + row;
-            tr[i] = m < mend ? *(const uint4*)(p.T + (size_t)m * p.ldt + ch * 8) : uint4{0u, 0u, 0u, 0u};
+            tr[slot][i] = m < mend ? *(const uint4*)(p.T + (size_t)m * p.ldt + ch * 8) : uint4{0u, 0u, 0u, 0u};
         }
     };
-    gload(0);
-    // (r03, measured and not kept: two steps of operands in flight + alternating partial-U sets for one barrier per step --
-    //  226 VGPRs and 144 KB of LDS leave the CU no room for the main stream's LayerNorm waves: 32.9 instead of 32.55 ms per step)
-    for (int t = 0; t < steps; ++t) {
+    auto step = [&](int t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
-        for (int i = 0; i < XL; ++i) { const int c = lane + 64 * i; *(uint4*)(xs + (c / CH) * XP + (c % CH) * 16) = xr[i]; }
+        for (int i = 0; i < XL; ++i) { const int c = lane + 64 * i; *(uint4*)(xs + (c / CH) * XP + (c % CH) * 16) = xr[slot][i]; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *(uint4*)(ts + (c >> 2) * TP + (c & 3) * 16) = tr[i]; }
+        for (int i = 0; i < 2; ++i) { const int c = lane + 64 * i; *(uint4*)(ts + (c >> 2) * TP + (c & 3) * 16) = tr[slot][i]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (t + 1 < steps) gload(t + 1);
+        if (t + DEPTH < steps) gload(t + DEPTH, slot_c);
         // dB[CPW columns of dY, 32] += dY^T . T over the 32 rows of this step
         const bf16x8 tf0 = tr_frag(ts, TP, 0, 0, lane), tf1 = tr_frag(ts, TP, 0, 16, lane);
 #pragma unroll
@@ -244,6 +252,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lora_bwd_fused_kernel(const Params
             }
         }
         __syncthreads();
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, DEPTH - 1>;
+    gload(0, S0{});
+    if (DEPTH == 2 && steps > 1) gload(1, S1{});
+    for (int t = 0; t < steps; t += DEPTH) {
+        step(t, S0{});
+        if (DEPTH == 2 && t + 1 < steps) step(t + 1, S1{});
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
