@@ -1,0 +1,36 @@
+"""The fused adapter-gradient kernel alone on the chip (step shape: 50 432 rows, N = 768, Rp = 32) against the two launches it replaces."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from prcv2025reid_amd import ops, _lib
+
+M, N, Rp, r = 50432, 768, 32, 8
+g = torch.Generator(device='cuda').manual_seed(0)
+dY = torch.randn(M, N, device='cuda', generator=g).to(_lib.t16())
+T = torch.randn(M, Rp, device='cuda', generator=g).to(_lib.t16())
+BT = (torch.randn(Rp, N, device='cuda', generator=g) * 0.1).to(_lib.t16())
+mods = torch.arange(256, device='cuda', dtype=torch.int32) // 64
+U = torch.empty(M, Rp, device='cuda', dtype=_lib.t16()); dB = torch.zeros(N, Rp, device='cuda')
+
+
+def timeit(fn, reps=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+for knob in (-1, 192, 768, 1536):
+    _lib.check(_lib.lib().reid_set_knob(b'TN_BLOCKS', knob))
+    t = timeit(lambda: ops.lora_bwd_fused(dY, T, BT, U, dB, mods, 197, r, 2.0))
+    slabs = 64 if knob < 0 else knob // 6
+    print(f'fused, {slabs:4d} slabs: {t:7.1f} us = {M * N * 2 / t / 1e6:7.2f} TB/s of dY = {M * N * 2 / t / 1e3 / slabs:6.1f} GB/s per workgroup')
+_lib.check(_lib.lib().reid_set_knob(b'TN_BLOCKS', -1))
+t1 = timeit(lambda: ops.gemm(dY, BT, U, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=197, alpha=2.0))
+t2 = timeit(lambda: ops.gemm_tn(dY, T, dB, beta=1.0))
+print(f'two launches: U {t1:.1f} us + dB {t2:.1f} us = {t1 + t2:.1f} us')
