@@ -30,6 +30,8 @@ class GalleryIndex:
         self.Gb = ops.to_t16(self.Gf)
         self.img_ids = None if img_ids is None else img_ids.to(self.Gf.device, torch.int32).contiguous()
         self._ws = None
+        self._exact_scratch = None
+        self.exact_slots = 256         # queries per large call that may take the exact fallback without a host read-back (None: read the flags back)
 
     def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False,
              query_img_ids: Optional[torch.Tensor] = None, stream: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -66,17 +68,34 @@ class GalleryIndex:
             scratch = torch.empty(Nq * Ng, dtype=torch.float32, device=Qf.device)
             ops.cosine_topk_exact(Qf, self.Gf, k, scratch, idx, sc, exclude_q=exq, exclude_g=exg)
             return idx, sc
+        # Large problems: candidate-list overflow (thousands of near-ties) flags a query with idx[q, 0] = -2.  The exact fp32 pass runs
+        # on a FIXED number of slots without reading the flags back (r02 synchronised here on every call): the F queries that sort
+        # first by "is flagged" are gathered, the exact kernels return at once for those that are not, and all F rows are written
+        # back (an unflagged row rewrites its own values).  More than F (default 256) flagged queries in one call -- a gallery
+        # with thousands of near-duplicates of hundreds of queries -- keep their -2 marker for the caller; ``exact_slots=None`` restores the read-back form that handles any number.
+        F = self.exact_slots
         flagged = (idx[:, 0] == -2)
-        if bool(flagged.any()):        # candidate-list overflow (thousands of near-ties): exact fp32 pass for those queries
-            rows = flagged.nonzero().flatten()
-            sub_q = Qf[rows].contiguous()
-            scratch = torch.empty(sub_q.shape[0] * Ng, dtype=torch.float32, device=Qf.device)
-            sidx = torch.full((sub_q.shape[0], k), -2, dtype=torch.int32, device=Qf.device)
-            ssc = torch.empty(sub_q.shape[0], k, dtype=torch.float32, device=Qf.device)
-            ops.cosine_topk_exact(sub_q, self.Gf, k, scratch, sidx, ssc,
-                                  exclude_q=None if exq is None else exq[rows].contiguous(), exclude_g=exg)
-            idx[rows] = sidx; sc[rows] = ssc
+        if F is None:
+            if bool(flagged.any()):
+                rows = flagged.nonzero().flatten()
+                self._exact_rows(Qf, rows, k, idx, sc, exq, exg)
+            return idx, sc
+        F = min(int(F), Nq)
+        rows = torch.topk(flagged.to(torch.int32), F, sorted=False).indices
+        self._exact_rows(Qf, rows, k, idx, sc, exq, exg)
         return idx, sc
+
+    def _exact_rows(self, Qf, rows, k, idx, sc, exq, exg):
+        Ng = self.Gf.shape[0]
+        sub_q = Qf[rows].contiguous()
+        need = sub_q.shape[0] * Ng
+        if self._exact_scratch is None or self._exact_scratch.numel() < need:
+            self._exact_scratch = torch.empty(need, dtype=torch.float32, device=Qf.device)
+        sidx = idx[rows].contiguous()                      # carries the -2 markers: unmarked rows are skipped by the kernels
+        ssc = sc[rows].contiguous()
+        ops.cosine_topk_exact(sub_q, self.Gf, k, self._exact_scratch, sidx, ssc,
+                              exclude_q=None if exq is None else exq[rows].contiguous(), exclude_g=exg)
+        idx[rows] = sidx; sc[rows] = ssc
 
 
 def cmc_from_topk(topk_idx: torch.Tensor, q_pids: torch.Tensor, g_pids: torch.Tensor, ks=(1, 5, 10)):

@@ -690,6 +690,47 @@ def test_cosine_topk_overflow_fallback_is_exact(ops, n_other):
         assert abs(float(sim[qi, a] - sim[qi, b])) < 2e-7, (qi, r, a, b)
 
 
+def test_cosine_topk_large_call_exact_slots_without_readback(ops):
+    """Large calls (> 2^26 scores) resolve candidate-list overflows on a fixed number of slots without reading the flags back:
+    up to ``exact_slots`` flagged queries are exact, more keep the -2 marker (visible to the caller), exact_slots=None reads the
+    flags back and resolves any number."""
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    g = torch.Generator(device='cuda').manual_seed(5)
+    D, Ng, k, n_over = 512, 30000, 10, 20
+    base = torch.nn.functional.normalize(torch.randn(1, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    G[10000:20000] = torch.nn.functional.normalize(base + 1e-3 * torch.randn(10000, D, device='cuda', generator=g), dim=1)
+    over = torch.nn.functional.normalize(base + 1e-4 * torch.randn(n_over, D, device='cuda', generator=g), dim=1)
+    Q = torch.cat([over, torch.nn.functional.normalize(torch.randn(2300, D, device='cuda', generator=g), dim=1)])
+    sim = Q.double() @ G.double().t()
+    ref = torch.argsort(sim.float(), dim=1, descending=True, stable=True)[:, :k]
+
+    def check_rows(idx, rows):
+        for qi, r in (ref[rows] != idx[rows].long()).nonzero().tolist():
+            q = int(rows[qi]); a, b = int(ref[q, r]), int(idx[q, r])
+            assert abs(float(sim[q, a] - sim[q, b])) < 2e-7, (q, r, a, b)
+
+    index = GalleryIndex(G, normalized=True)
+    assert index.exact_slots == 256
+    index.exact_slots = 1
+    idx1, _ = index.topk(Q, k=k, normalized=True)
+    n_flagged = int((idx1[:, 0] == -2).sum()) + 1         # the n_over near-copies and the random queries that score the whole cluster high
+    assert n_flagged >= n_over > 16
+    index.exact_slots = 16
+    idx, sc = index.topk(Q, k=k, normalized=True)
+    left = (idx[:, 0] == -2).nonzero().flatten()
+    assert left.numel() == n_flagged - 16
+    done = torch.tensor([q for q in range(Q.shape[0]) if q not in set(left.tolist())], device='cuda')
+    check_rows(idx, done)
+    index.exact_slots = None
+    idx2, sc2 = index.topk(Q, k=k, normalized=True)
+    assert int((idx2[:, 0] == -2).sum()) == 0
+    check_rows(idx2, torch.arange(Q.shape[0], device='cuda'))
+    index.exact_slots = 64
+    idx3, _ = index.topk(Q, k=k, normalized=True)
+    assert int((idx3[:, 0] == -2).sum()) == 0 and torch.equal(idx3, idx2)
+
+
 def test_sharded_gallery_single_process(ops):
     """ShardedGalleryIndex with one rank (no process group) == GalleryIndex on the whole gallery; offsets applied."""
     from prcv2025reid_amd.parallel import ShardedGalleryIndex, merge_topk
