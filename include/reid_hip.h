@@ -301,6 +301,12 @@ int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, co
 int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
                            const int32_t* exclude_q, const int32_t* exclude_g, float* scratch, int32_t* out_idx,
                            float* out_score, void* stream);
+/* The same exact pass without the [Nq, Ng] scratch and without reading the flags back: the flagged queries are compacted on the device
+ * into `slots` (int32 [1 + n_slots]: count, then query ids), at most n_slots of them are resolved (scratch: n_slots * Ng floats), any
+ * further flagged query keeps its -2 marker.  slots[0] afterwards = number of flagged queries (may exceed n_slots). */
+int reid_cosine_topk_exact_slots(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                                 const int32_t* exclude_q, const int32_t* exclude_g, int32_t n_slots, int32_t* slots,
+                                 float* scratch, int32_t* out_idx, float* out_score, void* stream);
 /* The reference's one-query-at-a-time form (tools/eval_mm_protocol.py:401-455: sim = q @ G.T; argsort) for a handful of
  * queries: ONE pass over the fp32 gallery (Ng*D*4 bytes, HBM-bound) instead of the batched pipeline's launch chain.  Same
  * fp32 scores and the same (score desc, index asc) lists as reid_cosine_topk.  Allowed when reid_topk_stream_ok() returns 1

@@ -39,7 +39,7 @@ EXPORTS = [
     'reid_attn_fwd', 'reid_attn_bwd', 'reid_cast_f32_bf16', 'reid_cast_bf16_f32', 'reid_gather_rows_f32',
     'reid_bnneck_stats', 'reid_bnneck_fwd', 'reid_bnneck_bwd_p1', 'reid_bnneck_bwd_p2',
     'reid_ce_ls_fwd', 'reid_ce_ls_bwd', 'reid_sdm_fwd', 'reid_sdm_bwd', 'reid_sdm_ws_floats',
-    'reid_topk_ws_bytes', 'reid_cosine_topk', 'reid_cosine_topk_exact', 'reid_l2norm_rows', 'reid_sgemm', 'reid_pack_bf16_table',
+    'reid_topk_ws_bytes', 'reid_cosine_topk', 'reid_cosine_topk_exact', 'reid_cosine_topk_exact_slots', 'reid_l2norm_rows', 'reid_sgemm', 'reid_pack_bf16_table',
     'reid_eltwise_f32', 'reid_small_attn_fwd', 'reid_small_attn_bwd', 'reid_masked_mean',
     'reid_opt_entry_bytes', 'reid_opt_ws_floats', 'reid_opt_state_floats', 'reid_opt_sumsq', 'reid_opt_clip', 'reid_opt_adamw',
     'reid_rank_metrics', 'reid_scatter_add_rows_f32', 'reid_embed_tokens',

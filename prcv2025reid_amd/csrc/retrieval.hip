@@ -330,16 +330,23 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Q
 
 // exact brute force for flagged queries, fp32 throughout: (1) scores of every gallery row, 64 workgroups per query;
 // (2) one workgroup per query extracts the k best by (score desc, index asc)
+// (slots != nullptr: blockIdx.y is a SLOT of the flagged-query list slots[1 + i], slots[0] = number of flagged queries; the scratch row
+//  is the slot's.  slots == nullptr: blockIdx.y is the query, flagged or not.)
 __global__ __launch_bounds__(256) void brute_score_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng, int D,
                                                           const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int k,
-                                                          const int32_t* __restrict__ out_idx, float* __restrict__ scratch) {
-    const int q = blockIdx.y;
+                                                          const int32_t* __restrict__ out_idx, float* __restrict__ scratch,
+                                                          const int32_t* __restrict__ slots, int n_slots) {
+    int q = blockIdx.y;
+    if (slots) {
+        if ((int)blockIdx.y >= min(slots[0], n_slots)) return;
+        q = slots[1 + blockIdx.y];
+    }
     if (out_idx[(size_t)q * k] != -2) return;
     __shared__ float qrow[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
     __syncthreads();
-    float* sc = scratch + (size_t)q * Ng;
+    float* sc = scratch + (size_t)(slots ? blockIdx.y : q) * Ng;
     const int eq = exq ? exq[q] : -1;
     for (int gi = blockIdx.x * 4 + w; gi < Ng; gi += gridDim.x * 4) {
         const float* g = Gf + (size_t)gi * D;
@@ -355,12 +362,16 @@ __global__ __launch_bounds__(256) void brute_score_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void brute_select_kernel(int Ng, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                           float* __restrict__ scratch) {
-    const int q = blockIdx.x;
+                                                           float* __restrict__ scratch, const int32_t* __restrict__ slots, int n_slots) {
+    int q = blockIdx.x;
+    if (slots) {
+        if ((int)blockIdx.x >= min(slots[0], n_slots)) return;
+        q = slots[1 + blockIdx.x];
+    }
     if (out_idx[(size_t)q * k] != -2) return;
     __shared__ float rbest[4]; __shared__ int ridx[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* sc = scratch + (size_t)q * Ng;
+    float* sc = scratch + (size_t)(slots ? blockIdx.x : q) * Ng;
     for (int r = 0; r < k; ++r) {
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int gi = tid; gi < Ng; gi += 256) {
@@ -958,9 +969,36 @@ extern "C" int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t 
                                       float* out_score, void* stream) {
     REID_CHECK_ARG(Qf && Gf && scratch && out_idx && out_score && Nq > 0 && Ng > 0 && k > 0 && k <= Ng && D % 4 == 0 && D <= 1024,
                    "reid_cosine_topk_exact: bad args");
-    hipLaunchKernelGGL(brute_score_kernel, dim3(64, Nq), dim3(256), 0, (hipStream_t)stream, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch);
+    hipLaunchKernelGGL(brute_score_kernel, dim3(64, Nq), dim3(256), 0, (hipStream_t)stream, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch,
+                       (const int32_t*)nullptr, 0);
     REID_CHECK_LAUNCH("reid_cosine_topk_exact(score)");
-    hipLaunchKernelGGL(brute_select_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, Ng, k, out_idx, out_score, scratch);
+    hipLaunchKernelGGL(brute_select_kernel, dim3(Nq), dim3(256), 0, (hipStream_t)stream, Ng, k, out_idx, out_score, scratch, (const int32_t*)nullptr, 0);
     REID_CHECK_LAUNCH("reid_cosine_topk_exact(select)");
+    return REID_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void flag_compact_kernel(const int32_t* __restrict__ out_idx, int Nq, int k, int32_t* __restrict__ slots, int n_slots) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Nq || out_idx[(size_t)q * k] != -2) return;
+    const int pos = atomicAdd(slots, 1);
+    if (pos < n_slots) slots[1 + pos] = q;
+}
+}  // namespace
+
+extern "C" int reid_cosine_topk_exact_slots(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
+                                            const int32_t* exclude_q, const int32_t* exclude_g, int32_t n_slots, int32_t* slots,
+                                            float* scratch, int32_t* out_idx, float* out_score, void* stream) {
+    REID_CHECK_ARG(Qf && Gf && scratch && slots && out_idx && out_score && Nq > 0 && Ng > 0 && k > 0 && k <= Ng && D % 4 == 0 && D <= 1024 &&
+                   n_slots > 0 && n_slots <= 65535, "reid_cosine_topk_exact_slots: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    REID_CHECK_HIP(hipMemsetAsync(slots, 0, sizeof(int32_t), s), "hipMemsetAsync");
+    hipLaunchKernelGGL(flag_compact_kernel, dim3((Nq + 255) / 256), dim3(256), 0, s, out_idx, Nq, k, slots, n_slots);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(compact)");
+    hipLaunchKernelGGL(brute_score_kernel, dim3(64, n_slots), dim3(256), 0, s, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch,
+                       (const int32_t*)slots, n_slots);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(score)");
+    hipLaunchKernelGGL(brute_select_kernel, dim3(n_slots), dim3(256), 0, s, Ng, k, out_idx, out_score, scratch, (const int32_t*)slots, n_slots);
+    REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(select)");
     return REID_OK;
 }

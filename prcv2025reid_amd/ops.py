@@ -324,6 +324,11 @@ def cosine_topk_exact(Qf, Gf, k, scratch, out_idx, out_score, exclude_q=None, ex
                                        ptr(exclude_g), ptr(scratch), ptr(out_idx), ptr(out_score), stream_ptr()))
 
 
+def cosine_topk_exact_slots(Qf, Gf, k, n_slots, slots, scratch, out_idx, out_score, exclude_q=None, exclude_g=None):
+    check(lib().reid_cosine_topk_exact_slots(ptr(Qf), ptr(Gf), Qf.shape[0], Gf.shape[0], Qf.shape[1], k, ptr(exclude_q), ptr(exclude_g),
+                                             n_slots, ptr(slots), ptr(scratch), ptr(out_idx), ptr(out_score), stream_ptr()))
+
+
 # ----------------------------------------------------------------------------------------- small fp32 head pieces
 ELT = {'add': 0, 'relu': 1, 'relu_bwd': 2, 'gelu': 3, 'gelu_bwd': 4, 'mul': 5, 'nan_to_num': 6, 'keep_mask': 7}
 

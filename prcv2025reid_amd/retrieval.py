@@ -31,6 +31,7 @@ class GalleryIndex:
         self.img_ids = None if img_ids is None else img_ids.to(self.Gf.device, torch.int32).contiguous()
         self._ws = None
         self._exact_scratch = None
+        self._slots = None             # device list of flagged queries of the last large call: [count, ids...]
         self.exact_slots = 256         # queries per large call that may take the exact fallback without a host read-back (None: read the flags back)
 
     def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False,
@@ -69,9 +70,8 @@ class GalleryIndex:
             ops.cosine_topk_exact(Qf, self.Gf, k, scratch, idx, sc, exclude_q=exq, exclude_g=exg)
             return idx, sc
         # Large problems: candidate-list overflow (thousands of near-ties) flags a query with idx[q, 0] = -2.  The exact fp32 pass runs
-        # on a FIXED number of slots without reading the flags back (r02 synchronised here on every call): the F queries that sort
-        # first by "is flagged" are gathered, the exact kernels return at once for those that are not, and all F rows are written
-        # back (an unflagged row rewrites its own values).  More than F (default 256) flagged queries in one call -- a gallery
+        # on a FIXED number of slots without reading the flags back (r02 synchronised here on every call): the flagged queries are
+        # compacted on the device (reid_cosine_topk_exact_slots), at most F of them are resolved, three small launches in all.  More than F (default 256) flagged queries in one call -- a gallery
         # with thousands of near-duplicates of hundreds of queries -- keep their -2 marker for the caller; ``exact_slots=None`` restores the read-back form that handles any number.
         F = self.exact_slots
         flagged = (idx[:, 0] == -2)
@@ -81,8 +81,12 @@ class GalleryIndex:
                 self._exact_rows(Qf, rows, k, idx, sc, exq, exg)
             return idx, sc
         F = min(int(F), Nq)
-        rows = torch.topk(flagged.to(torch.int32), F, sorted=False).indices
-        self._exact_rows(Qf, rows, k, idx, sc, exq, exg)
+        need = F * Ng
+        if self._exact_scratch is None or self._exact_scratch.numel() < need:
+            self._exact_scratch = torch.empty(need, dtype=torch.float32, device=Qf.device)
+        if self._slots is None or self._slots.numel() < F + 1:
+            self._slots = torch.empty(F + 1, dtype=torch.int32, device=Qf.device)
+        ops.cosine_topk_exact_slots(Qf, self.Gf, k, F, self._slots, self._exact_scratch, idx, sc, exclude_q=exq, exclude_g=exg)
         return idx, sc
 
     def _exact_rows(self, Qf, rows, k, idx, sc, exq, exg):
