@@ -396,6 +396,28 @@ def _pipeline_samples(seed, n_pid=9, image_size=224):
     return samples
 
 
+def _pipeline_perturb(samples, seed):
+    """Alternate spellings of the sample fields (same function in tests/test_data_cpu.py)."""
+    import random as pyrandom
+    R = pyrandom.Random(1000 + seed)
+    for s in samples:
+        if R.random() < 0.2:
+            s['mode'] = R.choice(['ir', 'x', 'sketch'])
+        if R.random() < 0.2:
+            s.pop('modality', None); s['mod'] = R.choice(['RGB', 'cp'])
+        if R.random() < 0.1:
+            s['images']['text'] = 'hello'
+        if R.random() < 0.1:
+            s['text_description'] = []
+        if R.random() < 0.1:
+            s['text_description'] = ['  ']
+        if R.random() < 0.1:
+            s['modality_mask']['cp'] = 2
+        if R.random() < 0.1:
+            s['modality_mask'] = {}
+    return samples
+
+
 def make_pipeline_cases():
     """pipeline_cases.json: the reference's own sampler and collate (datasets/dataset.py, pulled out by ``ast`` because the
     module imports torchvision) run on seeded synthetic samples: index lists of the strict P x K sampler under a seeded
@@ -445,8 +467,37 @@ def make_pipeline_cases():
                                'modality_mask': {m: v.tolist() for m, v in cb['modality_mask'].items()},
                                'image_sums': {m: [float(x) for x in v.double().flatten(1).sum(1)] for m, v in cb['images'].items()},
                                'image_shapes': {m: list(v.shape) for m, v in cb['images'].items()}})
+    # Variants (r04): alternate field names, odd captions, odd K, a subset of the indices, no identity reuse with as many batches as
+    # are certain to complete -- and what the reference infers per sample.
+    out['variants'] = []
+    for seed, P, K, reuse in ((10, 3, 4, True), (11, 2, 3, True), (12, 3, 2, False), (13, 2, 5, False), (14, 7, 2, True), (15, 3, 3, True)):
+        samples = _pipeline_perturb(_pipeline_samples(seed, n_pid=7), seed)
+        keep = [i for i in range(len(samples)) if (i * 7 + seed) % 5 != 0] if seed == 15 else list(range(len(samples)))
+
+        class Sub:                                         # what torch.utils.data.Subset looks like to the sampler
+            dataset = DS(samples)
+            indices = keep
+        sm = ns['ModalAwarePKBatchSampler_Strict'](Sub if seed == 15 else DS(samples), num_ids_per_batch=P, num_instances=K,
+                                                   allow_id_reuse=reuse)
+        if reuse:
+            n = 0 if (len(sm.strong_ids) < P and not sm.soft_ids) else 5
+        else:                                              # batches that complete before the reference starts retrying forever
+            n = (len(sm.strong_ids) + len(sm.soft_ids)) // P if (not sm.soft_ids or len(sm.strong_ids) % P == 0) else len(sm.strong_ids) // P
+        pyrandom.seed(200 + seed)
+        import itertools
+        batches = [list(map(int, b)) for b in itertools.islice(iter(sm), n)]
+        infer = [[sorted(ns['infer_modalities_of_sample'](DS(samples), i, include_text=t)) for t in (True, False)] for i in range(len(samples))]
+        case = {'seed': seed, 'P': P, 'K': K, 'reuse': reuse, 'rng_seed': 200 + seed, 'len': len(sm), 'keep': keep,
+                'strong_ids': list(map(int, sm.strong_ids)), 'soft_ids': list(map(int, sm.soft_ids)), 'batches': batches, 'infer': infer}
+        if batches:
+            cb = ns['compatible_collate_fn']([samples[i] for i in batches[0]])
+            case['collate'] = {'indices': batches[0], 'person_id': cb['person_id'].tolist(), 'text_description': cb['text_description'],
+                               'modality': cb['modality'], 'modality_mask': {m: v.tolist() for m, v in cb['modality_mask'].items()},
+                               'image_sums': {m: [float(x) for x in v.double().flatten(1).sum(1)] for m, v in cb['images'].items()}}
+        out['variants'].append(case)
     json.dump(out, open(os.path.join(HERE, 'pipeline_cases.json'), 'w'))
-    print(f"[pipeline] {sum(len(c['batches']) for c in out['sampler'])} sampler batches, {len(out['collate'])} collate cases")
+    print(f"[pipeline] {sum(len(c['batches']) for c in out['sampler'])} sampler batches, {len(out['collate'])} collate cases, "
+          f"{len(out['variants'])} variants with {sum(len(c['batches']) for c in out['variants'])} batches")
 
 
 # --------------------------------------------------------------------------- checkpoint layout

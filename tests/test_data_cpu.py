@@ -49,7 +49,7 @@ def make_samples(seed, n_pid=9, image_size=224):
 def test_sampler_reproduces_reference_draws(case):
     samples = make_samples(case['seed'])
     sm = D.StrictPKBatchSampler(samples, case['P'], case['K'], allow_id_reuse=case['reuse'], rng=random.Random(case['rng_seed']))
-    assert sm.strong_ids == case['strong_ids'] and sm.soft_ids == case['soft_ids'] and len(sm) == case['len']
+    assert sm.paired_ids == case["strong_ids"] and sm.unpaired_ids == case["soft_ids"] and len(sm) == case['len']
     got = []
     for b in sm:
         got.append(b)
@@ -76,6 +76,62 @@ def test_collate_matches_reference(case):
         assert list(b['images'][m].shape) == shp
         got = b['images'][m].double().flatten(1).sum(1).tolist()
         assert all(abs(x - y) <= 1e-9 * max(1.0, abs(y)) for x, y in zip(got, case['image_sums'][m])), m
+
+
+def perturb(samples, seed):
+    """Same function as tests/golden/make_golden.py::_pipeline_perturb."""
+    R = random.Random(1000 + seed)
+    for s in samples:
+        if R.random() < 0.2:
+            s['mode'] = R.choice(['ir', 'x', 'sketch'])
+        if R.random() < 0.2:
+            s.pop('modality', None); s['mod'] = R.choice(['RGB', 'cp'])
+        if R.random() < 0.1:
+            s['images']['text'] = 'hello'
+        if R.random() < 0.1:
+            s['text_description'] = []
+        if R.random() < 0.1:
+            s['text_description'] = ['  ']
+        if R.random() < 0.1:
+            s['modality_mask']['cp'] = 2
+        if R.random() < 0.1:
+            s['modality_mask'] = {}
+    return samples
+
+
+@pytest.mark.parametrize('case', CASES['variants'], ids=lambda c: f"seed{c['seed']}")
+def test_variants_match_reference(case):
+    """Alternate field spellings, odd captions, odd K, an index subset, no identity reuse: modality inference per sample, the identity
+    lists, every batch the reference completes, and the collate of the first batch."""
+    samples = perturb(make_samples(case['seed'], n_pid=7), case['seed'])
+    for i, s in enumerate(samples):
+        assert [sorted(D.infer_modalities(s, True)), sorted(D.infer_modalities(s, False))] == case['infer'][i], i
+    sm = D.StrictPKBatchSampler(samples, case['P'], case['K'], allow_id_reuse=case['reuse'], indices=case['keep'],
+                                rng=random.Random(case['rng_seed']))
+    assert sm.paired_ids == case['strong_ids'] and sm.unpaired_ids == case['soft_ids'] and len(sm) == case['len']
+    it = iter(sm)
+    got = [next(it) for _ in case['batches']]
+    assert got == case['batches']
+    if not case['reuse']:                                # where the reference starts retrying forever this iterator ends
+        rest = list(it)
+        assert len(rest) <= 1 and all(len(b) == case['P'] * case['K'] for b in rest)
+    if 'collate' in case:
+        c = case['collate']
+        b = D.collate([samples[i] for i in c['indices']])
+        assert b['person_id'].tolist() == c['person_id'] and b['text_description'] == c['text_description'] and b['modality'] == c['modality']
+        for m, v in c['modality_mask'].items():
+            assert b['modality_mask'][m].tolist() == v, m
+        for m, sums in c['image_sums'].items():
+            got_s = b['images'][m].double().flatten(1).sum(1).tolist()
+            assert all(abs(x - y) <= 1e-9 * max(1.0, abs(y)) for x, y in zip(got_s, sums)), m
+
+
+def test_sampler_ends_when_identities_run_out():
+    """Fewer identities than P and nothing to fill up with: the reference retries the same short batch forever; here the epoch ends."""
+    samples = make_samples(0, n_pid=2)
+    for reuse in (True, False):
+        sm = D.StrictPKBatchSampler([s for s in samples if int(s['person_id']) != 3], 4, 2, allow_id_reuse=reuse, rng=random.Random(0))
+        assert list(sm) == []
 
 
 def test_canon_and_infer():
