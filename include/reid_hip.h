@@ -301,9 +301,10 @@ int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, co
 int reid_cosine_topk_exact(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
                            const int32_t* exclude_q, const int32_t* exclude_g, float* scratch, int32_t* out_idx,
                            float* out_score, void* stream);
-/* The same exact pass without the [Nq, Ng] scratch and without reading the flags back: the flagged queries are compacted on the device
- * into `slots` (int32 [1 + n_slots]: count, then query ids), at most n_slots of them are resolved (scratch: n_slots * Ng floats), any
- * further flagged query keeps its -2 marker.  slots[0] afterwards = number of flagged queries (may exceed n_slots). */
+/* The same exact pass without reading the flags back: the flagged queries are compacted on the device into `slots` (int32 [1 + n_slots]:
+ * count, then query ids) and EVERY listed query is resolved by the one call -- list entry e uses scratch row e (scratch: n_slots * Ng
+ * floats; touched only for flagged queries).  n_slots >= Nq guarantees that no -2 marker survives the call; with a smaller list the
+ * queries beyond it keep their marker and slots[0] (> n_slots) says so. */
 int reid_cosine_topk_exact_slots(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,
                                  const int32_t* exclude_q, const int32_t* exclude_g, int32_t n_slots, int32_t* slots,
                                  float* scratch, int32_t* out_idx, float* out_score, void* stream);

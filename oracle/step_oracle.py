@@ -91,3 +91,90 @@ def warmup_cosine(total_epochs: int, warmup_epochs: int, start_factor=0.01, min_
         t = max(0, epoch - warmup_epochs)
         return min_factor + (1.0 - min_factor) * 0.5 * (1.0 + math.cos(math.pi * t / T))
     return lmbda
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N optimizer steps of the reference's loop (train.py:969-1045, the non-AMP branch the reference runs: use_amp=False,
+# train.py:1477-1479) on the CPU oracle: autograd through reid_oracle.forward / compute_loss, _sanitize_grads, the adaptive
+# clip rule fed by the total norm, torch.nn.utils.clip_grad_norm_, torch.optim.AdamW.step -- the library calls the reference
+# makes, on the reference's own parameter groups (tests/golden/learnable_params.json).  Used by tests/test_trajectory_gpu.py to
+# hold K steps of the HIP step driver against K steps of fp32 autograd.
+
+def ste_merged_linear(round_fn):
+    """A replacement for reid_oracle.mer_linear that evaluates MERLinear the way the HIP path does: ONE product with the merged
+    weight round_fn(W + (alpha/r) B A), while the gradient reaches A and B through the unrounded sum (straight-through) -- the
+    adapter gradients of the HIP path are formed from the unquantised function (csrc/lora.hip).  round_fn = identity restates
+    mer_linear exactly (up to fp32 summation order); round_fn = bf16 / f16 rounding isolates the effect of the merged operand's
+    rounding on a training trajectory from every other 16-bit rounding of the HIP path."""
+    def mer_linear(x, state, prefix, modality, scaling):
+        W = state[prefix + '.shared_linear.weight']
+        a = state[f'{prefix}.loras.{modality}.lora_A.weight']
+        bm = state[f'{prefix}.loras.{modality}.lora_B.weight']
+        wsum = W + scaling * (bm @ a)
+        weff = wsum + (round_fn(wsum.detach()) - wsum.detach())
+        return x @ weff.t() + state[prefix + '.shared_linear.bias']
+    return mer_linear
+
+
+ROUND_FN = {None: None, 'exact': lambda w: w, 'bf16': lambda w: w.to(torch.bfloat16).float(), 'f16': lambda w: w.half().float()}
+
+
+class TrajectoryOracle:
+    """state: reference-keyed fp32 tensors; groups: [{'name', 'lr', 'params': [keys]}] (the reference's inventory after its freeze
+    rule); every listed key trains, everything else is constant.  ``merged`` in ROUND_FN: None = MERLinear as the reference
+    writes it; 'exact' / 'bf16' / 'f16' = the merged-weight form with that rounding of the merged operand."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], arch, groups, *, weight_decay=1e-4, adaptive_clip=True, contrastive_weight=0.1,
+                 tau=0.2, ce_weight=1.0, use_sdm=True, merged=None, lr_scale=1.0, accum_steps=1, norm_every=200):
+        self.arch = arch
+        self.state = {k: v.detach().clone().float() if torch.is_tensor(v) and v.dtype.is_floating_point else v for k, v in state.items()}
+        self.groups = []
+        for g in groups:
+            ps = []
+            for k in g['params']:
+                if k not in self.state:                      # tensors the forward never reads (dead keys of the reference: no gradient,
+                    continue                                 # AdamW skips them there too)
+                self.state[k].requires_grad_(True)
+                ps.append(self.state[k])
+            if ps:
+                sc = lr_scale.get(g['name'], 1.0) if isinstance(lr_scale, dict) else lr_scale      # {group name: factor} or one factor
+                self.groups.append(dict(params=ps, lr=g['lr'] * sc, name=g['name']))
+        self.keys = [k for g in groups for k in g['params'] if k in self.state]
+        self.opt = torch.optim.AdamW(self.groups, weight_decay=weight_decay, foreach=False)
+        self.adaptive, self.history = adaptive_clip, []
+        self.loss_kw = dict(ce_weight=ce_weight, contrastive_weight=contrastive_weight, tau=tau, use_sdm=use_sdm)
+        self.merged = merged
+        self.accum_steps, self.norm_every = max(1, accum_steps), norm_every
+        self.batch_idx = 0
+        self.norms: List[float] = []
+
+    def step(self, images, tokens, masks, labels) -> Dict[str, float]:
+        from . import reid_oracle as O
+        bi = self.batch_idx
+        if bi % self.accum_steps == 0:
+            self.opt.zero_grad(set_to_none=True)
+        keep = O.mer_linear
+        if ROUND_FN[self.merged] is not None:
+            O.mer_linear = ste_merged_linear(ROUND_FN[self.merged])
+        try:
+            out = O.forward(self.state, self.arch, images, tokens, masks, True)
+            L = O.compute_loss(out, labels, **self.loss_kw)
+            (L['total_loss'] / self.accum_steps).backward()
+        finally:
+            O.mer_linear = keep
+        if (bi + 1) % self.accum_steps == 0:
+            ps = [self.state[k] for k in self.keys]
+            gr = [p.grad for p in ps if p.grad is not None]
+            sanitize_grads(gr)
+            n = total_norm(gr)
+            self.norms.append(n)
+            if self.adaptive:
+                if bi % self.norm_every == 0:
+                    self.history.append(n)
+                mx = adaptive_max_norm(self.history)
+            else:
+                mx = 0.5
+            torch.nn.utils.clip_grad_norm_(ps, max_norm=float(mx))
+            self.opt.step()
+        self.batch_idx += 1
+        return {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in L.items()}

@@ -330,70 +330,70 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ Q
 
 // exact brute force for flagged queries, fp32 throughout: (1) scores of every gallery row, 64 workgroups per query;
 // (2) one workgroup per query extracts the k best by (score desc, index asc)
-// (slots != nullptr: blockIdx.y is a SLOT of the flagged-query list slots[1 + i], slots[0] = number of flagged queries; the scratch row
-//  is the slot's.  slots == nullptr: blockIdx.y is the query, flagged or not.)
+// (slots != nullptr: the flagged queries are the list slots[1 .. slots[0]] (compacted on the device, slots[0] <= n_slots = capacity of the
+//  list); entry e uses scratch row e and is taken by workgroup row e % gridDim.y -- ANY number of flagged queries is resolved by the one
+//  launch, nothing is read back.  slots == nullptr: blockIdx.y is the query, flagged or not, and the scratch row is the query's.)
 __global__ __launch_bounds__(256) void brute_score_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng, int D,
                                                           const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int k,
                                                           const int32_t* __restrict__ out_idx, float* __restrict__ scratch,
                                                           const int32_t* __restrict__ slots, int n_slots) {
-    int q = blockIdx.y;
-    if (slots) {
-        if ((int)blockIdx.y >= min(slots[0], n_slots)) return;
-        q = slots[1 + blockIdx.y];
-    }
-    if (out_idx[(size_t)q * k] != -2) return;
     __shared__ float qrow[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
-    __syncthreads();
-    float* sc = scratch + (size_t)(slots ? blockIdx.y : q) * Ng;
-    const int eq = exq ? exq[q] : -1;
-    for (int gi = blockIdx.x * 4 + w; gi < Ng; gi += gridDim.x * 4) {
-        const float* g = Gf + (size_t)gi * D;
-        float s = 0.f;
-        for (int i = lane * 4; i < D; i += 256) {
-            const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
-            s = dot4_acc(s, a, b);
+    const int n_ent = slots ? min(slots[0], n_slots) : (int)gridDim.y;
+    for (int e = blockIdx.y; e < n_ent; e += gridDim.y) {
+        const int q = slots ? slots[1 + e] : e;
+        if (out_idx[(size_t)q * k] != -2) continue;                  // (workgroup-uniform)
+        __syncthreads();                                             // the previous entry's readers of qrow are done
+        for (int i = tid; i < D; i += 256) qrow[i] = Qf[(size_t)q * D + i];
+        __syncthreads();
+        float* sc = scratch + (size_t)e * Ng;
+        const int eq = exq ? exq[q] : -1;
+        for (int gi = blockIdx.x * 4 + w; gi < Ng; gi += gridDim.x * 4) {
+            const float* g = Gf + (size_t)gi * D;
+            float s = 0.f;
+            for (int i = lane * 4; i < D; i += 256) {
+                const f32x4 a = *(const f32x4*)(qrow + i), b = *(const f32x4*)(g + i);
+                s = dot4_acc(s, a, b);
+            }
+            s = wave_sum(s);
+            if (eq >= 0 && exg[gi] == eq) s = -1e9f;
+            if (lane == 0) sc[gi] = s;
         }
-        s = wave_sum(s);
-        if (eq >= 0 && exg[gi] == eq) s = -1e9f;
-        if (lane == 0) sc[gi] = s;
     }
 }
 
 __global__ __launch_bounds__(256) void brute_select_kernel(int Ng, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                            float* __restrict__ scratch, const int32_t* __restrict__ slots, int n_slots) {
-    int q = blockIdx.x;
-    if (slots) {
-        if ((int)blockIdx.x >= min(slots[0], n_slots)) return;
-        q = slots[1 + blockIdx.x];
-    }
-    if (out_idx[(size_t)q * k] != -2) return;
     __shared__ float rbest[4]; __shared__ int ridx[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* sc = scratch + (size_t)(slots ? blockIdx.x : q) * Ng;
-    for (int r = 0; r < k; ++r) {
-        float best = -INFINITY; int bi = 0x7fffffff;
-        for (int gi = tid; gi < Ng; gi += 256) {
-            const float s = sc[gi];
-            if (s > best || (s == best && gi < bi)) { best = s; bi = gi; }
-        }
+    const int n_ent = slots ? min(slots[0], n_slots) : (int)gridDim.x;
+    for (int e = blockIdx.x; e < n_ent; e += gridDim.x) {
+        const int q = slots ? slots[1 + e] : e;
+        if (out_idx[(size_t)q * k] != -2) continue;                  // (workgroup-uniform)
+        float* sc = scratch + (size_t)e * Ng;
+        for (int r = 0; r < k; ++r) {
+            float best = -INFINITY; int bi = 0x7fffffff;
+            for (int gi = tid; gi < Ng; gi += 256) {
+                const float s = sc[gi];
+                if (s > best || (s == best && gi < bi)) { best = s; bi = gi; }
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { rbest[w] = best; ridx[w] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int i = 1; i < 4; ++i)
+                    if (rbest[i] > rbest[0] || (rbest[i] == rbest[0] && ridx[i] < ridx[0])) { rbest[0] = rbest[i]; ridx[0] = ridx[i]; }
+                const bool ok = ridx[0] != 0x7fffffff;
+                out_idx[(size_t)q * k + r] = ok ? ridx[0] : -1;      // (r = 0 overwrites the -2 marker: tested once per entry, above)
+                out_score[(size_t)q * k + r] = ok ? rbest[0] : -INFINITY;
+                if (ok) sc[ridx[0]] = -INFINITY;
+            }
+            __syncthreads();
         }
-        if (lane == 0) { rbest[w] = best; ridx[w] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < 4; ++i)
-                if (rbest[i] > rbest[0] || (rbest[i] == rbest[0] && ridx[i] < ridx[0])) { rbest[0] = rbest[i]; ridx[0] = ridx[i]; }
-            const bool ok = ridx[0] != 0x7fffffff;
-            out_idx[(size_t)q * k + r] = ok ? ridx[0] : -1;
-            out_score[(size_t)q * k + r] = ok ? rbest[0] : -INFINITY;
-            if (ok) sc[ridx[0]] = -INFINITY;
-        }
-        __syncthreads();
     }
 }
 
@@ -990,15 +990,18 @@ extern "C" int reid_cosine_topk_exact_slots(const float* Qf, const float* Gf, in
                                             const int32_t* exclude_q, const int32_t* exclude_g, int32_t n_slots, int32_t* slots,
                                             float* scratch, int32_t* out_idx, float* out_score, void* stream) {
     REID_CHECK_ARG(Qf && Gf && scratch && slots && out_idx && out_score && Nq > 0 && Ng > 0 && k > 0 && k <= Ng && D % 4 == 0 && D <= 1024 &&
-                   n_slots > 0 && n_slots <= 65535, "reid_cosine_topk_exact_slots: bad args");
+                   n_slots > 0, "reid_cosine_topk_exact_slots: bad args");
     hipStream_t s = (hipStream_t)stream;
     REID_CHECK_HIP(hipMemsetAsync(slots, 0, sizeof(int32_t), s), "hipMemsetAsync");
     hipLaunchKernelGGL(flag_compact_kernel, dim3((Nq + 255) / 256), dim3(256), 0, s, out_idx, Nq, k, slots, n_slots);
     REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(compact)");
-    hipLaunchKernelGGL(brute_score_kernel, dim3(64, n_slots), dim3(256), 0, s, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch,
+    // workgroup rows walk the list with a stride: 256 rows in flight whatever the list's length (the usual length is 0: 256 x 64 workgroups
+    // that read one word and leave)
+    const int rows = n_slots < 256 ? n_slots : 256;
+    hipLaunchKernelGGL(brute_score_kernel, dim3(64, rows), dim3(256), 0, s, Qf, Gf, Ng, D, exclude_q, exclude_g, k, out_idx, scratch,
                        (const int32_t*)slots, n_slots);
     REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(score)");
-    hipLaunchKernelGGL(brute_select_kernel, dim3(n_slots), dim3(256), 0, s, Ng, k, out_idx, out_score, scratch, (const int32_t*)slots, n_slots);
+    hipLaunchKernelGGL(brute_select_kernel, dim3(rows), dim3(256), 0, s, Ng, k, out_idx, out_score, scratch, (const int32_t*)slots, n_slots);
     REID_CHECK_LAUNCH("reid_cosine_topk_exact_slots(select)");
     return REID_OK;
 }

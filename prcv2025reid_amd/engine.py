@@ -153,6 +153,11 @@ class Engine:
         self._text_packed = None
         self.overlap_tn = os.environ.get('REID_TN_STREAM', '1') != '0'
         self.cls_prune = os.environ.get('REID_CLS_PRUNE', '1') != '0'
+        # experiment switches, read once (the per-layer code paths test attributes, not the environment)
+        self.add_ln = os.environ.get('REID_ADD_LN', '1') != '0'
+        self.lora_down_defer = os.environ.get('REID_LORA_DOWN_DEFER', '1') != '0'
+        self.lora_fused = os.environ.get('REID_LORA_FUSED', '1') != '0'
+        self.lora_fused_max_n = 768 if os.environ.get('REID_LORA_FUSED') == '768' else 1 << 30      # (A/B: only the 768-column linears)
         self.W = {}
         self.W32 = {}
 
@@ -252,6 +257,9 @@ class Engine:
         main = torch.cuda.current_stream(self.dev)
         ps = self._pack_stream()
         ev = torch.cuda.Event(); ev.record(main); ps.wait_event(ev)
+        if self._side is not None:
+            # deferred T = x A^T launches of a forward whose backward never ran may still be reading the 16-bit adapter pack
+            ev_s = torch.cuda.Event(); ev_s.record(self._side); ps.wait_event(ev_s)
         with torch.cuda.stream(ps):
             ops.pack_bf16_table(arena, self._lora_pack, self._table, self._table.shape[0])
             ops.merge_lora_table(self._merge_table, self._merge_table.shape[0], self._merge_tiles, arena, self._weff, lay.Rp, lay.r,
@@ -376,7 +384,7 @@ class Engine:
 
         # Residual adds live in the LayerNorm that follows them (reid_add_layernorm_fwd): the out-projection and fc2 GEMMs store their
         # 16-bit branch output, the add + LN kernel streams x once.  LN1 of block l+1 is therefore produced at the end of block l.
-        add_ln = os.environ.get('REID_ADD_LN', '1') != '0'
+        add_ln = self.add_ln
         L = a['vision_layers']
         nxt = None
         for l in range(L):
@@ -425,7 +433,7 @@ class Engine:
                 T1 = torch.empty(Mr, Rp, **b16); T2 = torch.empty(Mr, Rp, **b16)
                 lora_down([(h, pk(l, 'qkv', 'A'), T, mk), (oin, pk(l, 'out', 'A'), To, mkr), (h2, pk(l, 'fc1', 'A'), T1, mkr),
                            (g, pk(l, 'fc2', 'A'), T2, mkr)])
-                if side is not None and os.environ.get('REID_LORA_DOWN_DEFER', '1') == '0':
+                if side is not None and not self.lora_down_defer:
                     flush_lora_down()
             xn = torch.empty(Mr, d, **f32) if save else new('xn' + str(l & 1) + ('c' if last else ''), (Mr, d), f32)
             if add_ln and not last and l + 1 < L:
@@ -448,7 +456,7 @@ class Engine:
                           row_index=None if self.cls_prune else idx)
         feats = torch.empty(n_img, a['fusion_dim'], **f32)
         ops.gemm(cls_h, W['vproj'], feats)
-        if os.environ.get('REID_LORA_DOWN_DEFER', '1') != '0':
+        if self.lora_down_defer:
             flush_lora_down()
         state = dict(layers=saved, x_final=x, idx=idx, idxl=idxl, mf=mf, rf=rf, img_mod=img_mod, n_img=n_img, cls_h=cls_h,
                      groups=groups, cls_prune=self.cls_prune, rg_full=rg_full, rg_cls=rg_cls) if save else None
@@ -547,9 +555,18 @@ class Engine:
             if cur_dxb is not dxb:
                 cur_dxb.copy_(dxb)
 
-        fuse_u_db = os.environ.get('REID_LORA_FUSED', '1') != '0'
-        fuse_max_n = 768 if os.environ.get('REID_LORA_FUSED') == '768' else 1 << 30      # (A/B: only the 768-column linears)
+        fuse_u_db, fuse_max_n = self.lora_fused, self.lora_fused_max_n
         u_part = torch.empty(M, Rp, **f32) if fuse_u_db else None      # fp32 partial U of fc1's four column blocks (side stream only)
+        # Class-row scratch of the pruned last block.  Read and written by the SIDE stream (lora_grads) long after the main stream has
+        # moved on, so it must not be released inside the loop: a block freed by the main stream is handed to the main stream's next
+        # allocation at once (wgrad / colsum / ln_grads with want_dense), whatever other streams still have pending on it (r03 found
+        # this hazard for forward-only calls).  Allocated here, these tensors die when this function returns -- after the join of the
+        # side stream into the main stream below has been enqueued, which orders every later main-stream use behind the side kernels.
+        cls_tmp = None
+        if prune:
+            cls_tmp = dict(U2=torch.empty(n_img, Rp, **b16), U1=torch.empty(n_img, Rp, **b16), Uo=torch.empty(n_img, Rp, **b16),
+                           du=torch.empty(n_img, ff, **b16), dh=torch.empty(n_img, d, **b16), do=torch.empty(n_img, d, **b16),
+                           dxm=torch.empty(n_img, d, **f32), dxmb=torch.empty(n_img, d, **b16))
 
         def lora_grads(l, calls):
             """Adapter gradients of one linear on the side stream: U = mask(dY . Bcat) * (alpha/r), dB += dY^T T, dA += U^T X.
@@ -594,9 +611,7 @@ class Engine:
                 Mr, rg = n_img, rg_cls
                 mkr = dict(img_mod=st['img_mod'], mask_r=r, mask_period=Rp, rows_per_img=1, alpha=self.scaling)
                 gy, gyb = dx_c, dxb_c
-                U2r = torch.empty(Mr, Rp, **b16); U1r = torch.empty(Mr, Rp, **b16); Uor = torch.empty(Mr, Rp, **b16)
-                dur = torch.empty(Mr, ff, **b16); dhr = torch.empty(Mr, d, **b16); dor = torch.empty(Mr, d, **b16)
-                dxmr = torch.empty(Mr, d, **f32); dxmbr = torch.empty(Mr, d, **b16)
+                U2r, U1r, Uor, dur, dhr, dor, dxmr, dxmbr = (cls_tmp[k_] for k_ in ('U2', 'U1', 'Uo', 'du', 'dh', 'do', 'dxm', 'dxmb'))
                 rpi = 1
             else:
                 Mr, mkr, gy, gyb, rg = M, mk, dx, dxb2[b], rg_full

@@ -297,7 +297,9 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         _lib.set_flavor(self.compute_dtype)
         self.engine.refresh()
         ids, am = self._tokens(texts)
-        return self._text_apply(ids, am)
+        out = self._text_apply(ids, am)
+        self.engine.wait_packed()
+        return out
 
     def seed_stochastic(self, seed: int, rank: int = 0):
         """Reseed the regularisers' generators (head masks identical on every rank, DropPath per rank)."""
@@ -553,6 +555,9 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
             raw['text'] = tf; fmask['text'] = tmd
         if not raw:
             raise ValueError('at least one modality is required')
+        # a step without any vision pass (text-only batch) has not joined the weight pack of engine.refresh(): the optimizer must not
+        # write the adapter arena while the pack stream still reads it (no-op when the vision pass has already waited)
+        self.engine.wait_packed()
         if gather_fn is not None:
             raw, fmask = gather_fn(raw, fmask)
         if self.training:

@@ -32,13 +32,17 @@ class GalleryIndex:
         self._ws = None
         self._exact_scratch = None
         self._slots = None             # device list of flagged queries of the last large call: [count, ids...]
-        self.exact_slots = 256         # queries per large call that may take the exact fallback without a host read-back (None: read the flags back)
+        # Large calls resolve candidate-list overflows (queries flagged idx[q, 0] = -2) on the device, without reading the flags back:
+        # the exact pass owns one scratch row of Ng floats per QUERY of the call (untouched unless the query is flagged), so a call is cut
+        # into query chunks whose scratch stays below this many bytes (10k x 200k: 8 GB of the 288 GB, one chunk).
+        self.exact_scratch_bytes = 16 << 30
 
     def topk(self, queries: torch.Tensor, k: int = 10, normalized: bool = False,
              query_img_ids: Optional[torch.Tensor] = None, stream: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(indices int32 [Nq, k], scores f32 [Nq, k]); entries whose img id equals the query's are excluded
         (same-image mask of eval_mm_protocol.py:421-422) when both id vectors are given.  ``stream``: force the one-pass
-        form for a few queries (True) or the batched MFMA pipeline (False); default: whichever fits the shape."""
+        form for a few queries (True) or the batched MFMA pipeline (False); default: whichever fits the shape.
+        Index -1 = no entry (fewer than k gallery rows); no other negative value is ever returned."""
         Qf = queries.contiguous().float()
         if not normalized:
             Qf = l2_normalize(Qf)
@@ -57,6 +61,18 @@ class GalleryIndex:
             sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
             ops.cosine_topk_stream(Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
             return idx, sc
+        chunk = max(1, int(self.exact_scratch_bytes // (4 * Ng)))
+        if Nq > chunk and Nq * Ng > (1 << 26):
+            idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
+            sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
+            for q0 in range(0, Nq, chunk):
+                i_, s_ = self._topk_batched(Qf[q0:q0 + chunk], k, None if exq is None else exq[q0:q0 + chunk], exg)
+                idx[q0:q0 + chunk] = i_; sc[q0:q0 + chunk] = s_
+            return idx, sc
+        return self._topk_batched(Qf, k, exq, exg)
+
+    def _topk_batched(self, Qf, k, exq, exg):
+        Nq, Ng = Qf.shape[0], self.Gf.shape[0]
         Qb = ops.to_t16(Qf)
         need = ops.topk_ws_bytes(Nq, Ng, k)
         if self._ws is None or self._ws.numel() < need:
@@ -69,37 +85,16 @@ class GalleryIndex:
             scratch = torch.empty(Nq * Ng, dtype=torch.float32, device=Qf.device)
             ops.cosine_topk_exact(Qf, self.Gf, k, scratch, idx, sc, exclude_q=exq, exclude_g=exg)
             return idx, sc
-        # Large problems: candidate-list overflow (thousands of near-ties) flags a query with idx[q, 0] = -2.  The exact fp32 pass runs
-        # on a FIXED number of slots without reading the flags back (r02 synchronised here on every call): the flagged queries are
-        # compacted on the device (reid_cosine_topk_exact_slots), at most F of them are resolved, three small launches in all.  More than F (default 256) flagged queries in one call -- a gallery
-        # with thousands of near-duplicates of hundreds of queries -- keep their -2 marker for the caller; ``exact_slots=None`` restores the read-back form that handles any number.
-        F = self.exact_slots
-        flagged = (idx[:, 0] == -2)
-        if F is None:
-            if bool(flagged.any()):
-                rows = flagged.nonzero().flatten()
-                self._exact_rows(Qf, rows, k, idx, sc, exq, exg)
-            return idx, sc
-        F = min(int(F), Nq)
-        need = F * Ng
+        # Large problems: the flagged queries are compacted into a device list and ALL of them take the exact fp32 pass -- three small
+        # launches, nothing read back (r02 synchronised here on every call; r03 resolved at most 256 and left the rest marked).
+        need = Nq * Ng
         if self._exact_scratch is None or self._exact_scratch.numel() < need:
+            self._exact_scratch = None
             self._exact_scratch = torch.empty(need, dtype=torch.float32, device=Qf.device)
-        if self._slots is None or self._slots.numel() < F + 1:
-            self._slots = torch.empty(F + 1, dtype=torch.int32, device=Qf.device)
-        ops.cosine_topk_exact_slots(Qf, self.Gf, k, F, self._slots, self._exact_scratch, idx, sc, exclude_q=exq, exclude_g=exg)
+        if self._slots is None or self._slots.numel() < Nq + 1:
+            self._slots = torch.empty(Nq + 1, dtype=torch.int32, device=Qf.device)
+        ops.cosine_topk_exact_slots(Qf, self.Gf, k, Nq, self._slots, self._exact_scratch, idx, sc, exclude_q=exq, exclude_g=exg)
         return idx, sc
-
-    def _exact_rows(self, Qf, rows, k, idx, sc, exq, exg):
-        Ng = self.Gf.shape[0]
-        sub_q = Qf[rows].contiguous()
-        need = sub_q.shape[0] * Ng
-        if self._exact_scratch is None or self._exact_scratch.numel() < need:
-            self._exact_scratch = torch.empty(need, dtype=torch.float32, device=Qf.device)
-        sidx = idx[rows].contiguous()                      # carries the -2 markers: unmarked rows are skipped by the kernels
-        ssc = sc[rows].contiguous()
-        ops.cosine_topk_exact(sub_q, self.Gf, k, self._exact_scratch, sidx, ssc,
-                              exclude_q=None if exq is None else exq[rows].contiguous(), exclude_g=exg)
-        idx[rows] = sidx; sc[rows] = ssc
 
 
 def cmc_from_topk(topk_idx: torch.Tensor, q_pids: torch.Tensor, g_pids: torch.Tensor, ks=(1, 5, 10)):
@@ -107,6 +102,8 @@ def cmc_from_topk(topk_idx: torch.Tensor, q_pids: torch.Tensor, g_pids: torch.Te
     gallery's identity histogram ([max pid + 1] counts), not an [Nq, Ng] comparison (2 GB at 10k x 200k)."""
     dev = topk_idx.device
     gp = g_pids.to(dev).long(); qp = q_pids.to(dev).long()
+    if bool((topk_idx < -1).any()):                       # (this function synchronises anyway: the metrics go to the host)
+        raise ValueError('cmc_from_topk: rank list holds an unresolved marker (index < -1)')
     hit = gp[topk_idx.long().clamp_min(0)] == qp.view(-1, 1)
     hit &= topk_idx >= 0                                  # (-1 = no entry: fewer than k gallery rows)
     lo = int(min(int(gp.min()), int(qp.min()))) if gp.numel() and qp.numel() else 0

@@ -377,6 +377,46 @@ def test_vision_backbone_gradients_random_cotangent(flavor, tol):
     print(f'  [{flavor}] {n} backbone tensors, worst grad rel-L2 = {worst:.3e}')
 
 
+def test_dense_gradients_independent_of_side_stream_timing():
+    """freeze_backbone=False with the class-row pruning of the last block on: the class-row scratch of that block is read by the
+    adapter-gradient SIDE stream while the main stream goes on allocating (weight gradients, column sums, LayerNorm pairs).  The side
+    stream is held back by ~20 ms of sleep so that every one of its kernels is still pending when the main stream has finished
+    allocating; gradients must equal those of the same backward run on ONE stream (r03 hazard: blocks released inside the loop)."""
+    z, meta = load_case('tiny_train_all')
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    g = torch.Generator().manual_seed(23)
+    imgs = {m: torch.randn(3, 3, 224, 224, generator=g) for m in ('vis', 'nir', 'sk', 'cp')}
+    R = torch.randn(12, 512, generator=g).cuda()
+    grads = {}
+    for mode in ('one_stream', 'side_delayed'):
+        model = build_model(meta, state, True, 'bf16')
+        assert model.engine.cls_prune
+        for k, p in model.named_parameters():
+            p.requires_grad_(not k.startswith('clip_encoder.clip_model.') and k != 'clip_encoder.text_proj.weight')
+        model.engine.overlap_tn = mode == 'side_delayed'
+        model.engine.refresh()
+        feats = model._vision_apply(tuple(model.vision_modalities.index(m) for m in imgs), [imgs[m].cuda() for m in imgs])
+        if mode == 'side_delayed':
+            with torch.cuda.stream(model.engine._side_stream()):
+                torch.cuda._sleep(40_000_000)
+        (feats * R).sum().backward()
+        torch.cuda.synchronize()
+        P = dict(model.named_parameters())
+        grads[mode] = {k: P[k].grad.detach().clone() for k in model.engine.vision_dense_keys() if P[k].grad is not None}
+        grads[mode]['lora_arena'] = model.lora_arena.grad.detach().clone()
+    assert len(grads['one_stream']) >= 30 and grads['one_stream'].keys() == grads['side_delayed'].keys()
+    worst = 0.0
+    for k, a in grads['one_stream'].items():
+        b = grads['side_delayed'][k]
+        if float(a.abs().max()) < 1e-12:
+            assert float(b.abs().max()) < 1e-9, k
+            continue
+        e = l2rel(b.cpu(), a.cpu())
+        worst = max(worst, e)
+        assert e < 1e-5, (k, e)                          # same kernels, same inputs: only the order of the fp32 atomics differs
+    print(f'  {len(grads["one_stream"])} gradient tensors, worst rel-L2 between the two schedules = {worst:.2e}')
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Reference quirks of forward() and the batch-level modality dropout, on the HIP model, against fixtures the reference
 # itself produced (tests/golden/make_golden.py --only edge).
