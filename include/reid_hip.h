@@ -32,7 +32,10 @@ typedef enum {
     REID_ERR_DEVICE = -3    /* not a gfx950 device                         */
 } reid_status;
 
-typedef enum { REID_BF16 = 0, REID_F32 = 1 } reid_dtype;
+/* REID_BF16 = the 16-bit format of the library flavor (see reid_flavor); REID_F16 = IEEE half WHATEVER the flavor, with saturating
+ * conversion (a finite value beyond +-65504 is stored as +-65504): accepted only where an entry point says so -- for tensors that are
+ * not MFMA operands, where half's 11 significant bits cost nothing (the residual-branch output between a GEMM and the add + LayerNorm). */
+typedef enum { REID_BF16 = 0, REID_F32 = 1, REID_F16 = 2 } reid_dtype;
 
 typedef enum {
     REID_ACT_NONE = 0,
@@ -136,8 +139,9 @@ int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, co
 /* Residual add fused into the LayerNorm that follows it (models/clip_backbone.py:76 -> :82, :83 -> next block's :73):
  *   x_out = x + row_scale[row / rows_per_img] * y        (x f32, y = the 16-bit branch output of reid_mer_gemm; row_scale NULL = 1:
  *                                                         DropPath, clip_backbone.py:137-141);  h = LayerNorm(x_out) in 16 bits,
- *   mean / rstd of x_out saved for the backward pass.  x_out may alias x. */
-int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t ldy, const float* row_scale, int32_t rows_per_img,
+ *   mean / rstd of x_out saved for the backward pass.  x_out may alias x.  y_dtype: REID_BF16 (the flavor's format) or REID_F16
+ *   (IEEE half whatever the flavor: what reid_mer_gemm stores with c_dtype = REID_F16). */
+int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t y_dtype, int32_t ldy, const float* row_scale, int32_t rows_per_img,
                            float* x_out, int32_t ldxo, const float* gamma, const float* beta, void* h_bf16, int32_t ldh,
                            float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,

@@ -30,7 +30,7 @@ def t16() -> torch.dtype:
     return T16_DTYPES[_flavor]
 
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2          # reid_dtype: BF16 = the flavor's 16-bit format, F16 = IEEE half whatever the flavor
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_DGELU, ACT_DQUICK_GELU, ACT_DRELU, ACT_MUL_AUX, ACT_GELU_DSAVE = range(9)
 
 EXPORTS = [
@@ -106,9 +106,11 @@ def ptr(t):
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
 
-def dt(t) -> int:
+def dt(t, allow_half: bool = False) -> int:
     if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
         if t.dtype != t16():
+            if allow_half and t.dtype == torch.float16:          # an IEEE-half tensor in the bf16 flavor (REID_F16: not an MFMA operand)
+                return F16
             raise TypeError(f'{t.dtype} tensor passed to the {_flavor} flavor of libreid_hip')
         return BF16
     if t.dtype == torch.float32:

@@ -483,6 +483,475 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward: one pass (r04)
+// dQ, dK and dV of one (sequence, head) from ONE staging of Q, K, V and dO (the two kernels above each stage half of them and
+// each read dO / Q / K / V again: 8 LDS-DMA head images and ~930 MB of HBM traffic per ViT layer where 4 images and ~620 MB do).
+// One workgroup holds the four swizzled images (4 x NT x 4 KiB = 112 KiB at S = 197) and runs, without any barrier between them,
+//   phase 1 -- wave w owns KEY tile w (keys on the lane):  S = Q K^T, dP = dO V^T per query tile -> dV^T += dO^T P, dK^T += Q^T dS
+//   phase 2 -- wave w owns QUERY tile w (queries on the lane):  S^T = K Q^T, dP^T = V dO^T per key tile -> dQ^T += K^T dS^T
+// i.e. the products of the two kernels above, fed from LDS.  delta = rowsum(dO . O) is formed first by the query-owning waves (O is
+// read once, from global memory) and shared through LDS with the saved log-sum-exp.
+// In-wave pipelining: the S / dP MFMAs of tile t + 1 are issued BEFORE the exponentials of tile t (two accumulator sets), so that
+// a wave's matrix work does not wait behind its own exp -> pack -> MFMA chain (r03: with one workgroup per CU that chain is exposed).
+// No key mask / causal form: the text tower's backward (rare: freeze_text_backbone=False) keeps the two-kernel path.
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParams p) {
+    REID_T16_ENTER();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = NT * 32 * 128;
+    char* Qs = smem;
+    char* Gs = smem + IMG;                           // dO
+    char* Ks = smem + 2 * IMG;
+    char* Vs = smem + 3 * IMG;
+    float* rowc = (float*)(smem + 4 * IMG);          // [2][NT*32]: -lse * log2(e), -delta / 8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int d = p.heads * 64;
+    const bf16_t* qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+    const bf16_t* gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
+    const bf16_t* ob = p.out + (size_t)seq * p.S * p.ldo + head * 64;
+    const int nq = p.q_tiles > 0 ? (p.q_tiles < NT ? p.q_tiles : NT) : NT;     // query tiles that take part (class-row pruning)
+    const int q_rows = nq * 32;
+    // all four head images in flight at once (16 LDS-DMA instructions per wave)
+    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane, q_rows);
+    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane, q_rows);
+    stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);
+    stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
+    const int t0 = wave * 32;                        // first row of this wave's tile (key tile in phase 1, query tile in phase 2)
+    const int ti = t0 + (lane & 31);
+    const int trow = ti < p.S ? ti : p.S - 1;
+    const bool own_q = wave < nq && t0 < p.S;        // wave-uniform: this wave's QUERY tile takes part
+    // delta of this wave's query rows: O fragments straight from global memory (their latency hides behind the image staging)
+    bf16x8 of[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) of[ks] = gfrag(ob, p.ldo, trow, 2 * ks, lane);
+    const size_t so = ((size_t)seq * p.heads + head) * p.S + trow;
+    const float lse_v = p.lse[so];
+    const FragOff fo = make_frag_off(lane);
+    __syncthreads();                                 // vmcnt(0) + barrier: the images are in LDS
+    {
+        float dsum = 0.f;
+        if (own_q) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 gfk = row_frag_o(Gs, t0, ks, fo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(bf16_to_f32((bf16_t)gfk[j]), bf16_to_f32((bf16_t)of[ks][j]), dsum);
+            }
+        }
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (lane < 32) {
+            const bool live = own_q && ti < p.S;     // padded / pruned query rows: P = exp2(-inf) = 0
+            rowc[ti] = live ? -lse_v * LOG2E : -INFINITY;
+            rowc[NT * 32 + ti] = live ? -dsum * 0.125f : 0.f;
+            if (live && p.delta) p.delta[so] = dsum;
+        }
+    }
+    __syncthreads();
+    if (t0 >= p.S) return;                           // (wave-uniform; no barrier follows)
+    const float c = 0.125f * LOG2E;
+    const int h4 = 4 * (lane >> 5);
+    const bool tile_ok = ti < p.S;
+
+    // ------------------------------------------------------------------ phase 1: this wave's key tile
+    {
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag_o(Ks, t0, ks, fo); vf[ks] = row_frag_o(Vs, t0, ks, fo); }
+        f32x16 dkt[2], dvt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
+        const int nqt = nq < (p.S + 31) / 32 ? nq : (p.S + 31) / 32;      // query tiles with at least one real row
+        auto scores = [&](int qt, f32x16& s, f32x16& dp) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(row_frag_o(Qs, qt * 32, ks, fo), kf[ks], s);
+                dp = mfma32(row_frag_o(Gs, qt * 32, ks, fo), vf[ks], dp);
+            }
+        };
+        f32x16 s, dp, s_n, dp_n;
+        if (nqt > 0) scores(0, s, dp);
+        for (int qt = 0; qt < nqt; ++qt) {
+            if (qt + 1 < nqt) scores(qt + 1, s_n, dp_n);          // next tile's matrix work first: it runs under this tile's exponentials
+            // one 16-row half of the tile at a time, packed to 16 bits at once (P and dS never exist as two fp32 tiles: registers)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * s2 + g2;
+                    const f32x4 nl = *(const f32x4*)(rowc + qt * 32 + 8 * g + h4);
+                    const f32x4 nd = *(const f32x4*)(rowc + NT * 32 + qt * 32 + 8 * g + h4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g + j;
+                        const float pe = fast_exp2(fmaf(s[e], c, nl[j]));
+                        pf[4 * g2 + j] = (short)f32_to_bf16(pe);
+                        df[4 * g2 + j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd[j]));
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dvt[dt] = mfma32(col_frag_o(Gs, qt * 32 + 16 * s2, dt, fo), pf, dvt[dt]);
+                    dkt[dt] = mfma32(col_frag_o(Qs, qt * 32 + 16 * s2, dt, fo), df, dkt[dt]);
+                }
+            }
+            s = s_n; dp = dp_n;
+        }
+        bf16_t* drow = p.dqkv + ((size_t)seq * p.S + trow) * p.lddqkv + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            store_tile_row16(drow + d + dt * 32, tile_ok, dkt[dt], 1.0f, lane);
+            store_tile_row16(drow + 2 * d + dt * 32, tile_ok, dvt[dt], 1.0f, lane);
+        }
+    }
+
+    // ------------------------------------------------------------------ phase 2: this wave's query tile
+    bf16_t* qrow_out = p.dqkv + ((size_t)seq * p.S + trow) * p.lddqkv + head * 64;
+    if (!own_q) {                                    // query tile left out by q_tiles: its dQ rows are exactly zero
+        if (tile_ok) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(uint2*)(qrow_out + dt * 32 + 8 * g + 4 * (lane >> 5)) = uint2{0u, 0u};
+        }
+        return;
+    }
+    {
+        bf16x8 qf[4], gf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag_o(Qs, t0, ks, fo); gf[ks] = row_frag_o(Gs, t0, ks, fo); }
+        const float nl = rowc[ti], nd = rowc[NT * 32 + ti];
+        f32x16 dqt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+        const int nkt = (p.S + 31) / 32;
+        auto scores_t = [&](int kt, f32x16& s, f32x16& dp) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], s);
+                dp = mfma32(row_frag_o(Vs, kt * 32, ks, fo), gf[ks], dp);
+            }
+        };
+        f32x16 s, dp, s_n, dp_n;
+        scores_t(0, s, dp);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) scores_t(kt + 1, s_n, dp_n);
+            const bool edge = (kt + 1) * 32 > p.S;    // only the last key tile holds padded keys
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 df;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * s2 + j;
+                    float pe = fast_exp2(fmaf(s[e], c, nl));
+                    if (edge) {
+                        const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+                        pe = key < p.S ? pe : 0.f;
+                    }
+                    df[j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd));
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dqt[dt] = mfma32(col_frag_o(Ks, kt * 32 + 16 * s2, dt, fo), df, dqt[dt]);
+            }
+            s = s_n; dp = dp_n;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) store_tile_row16(qrow_out + dt * 32, tile_ok, dqt[dt], 1.0f, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: one pass, PERSISTENT (r04)
+// The kernel above is bound by what happens BETWEEN items: 112 KiB of LDS images = one workgroup per CU, so the ~4 us it takes the four
+// images to land is exposed once per (sequence, head) -- about as long as the item's arithmetic.  Here one workgroup per CU walks the items
+// (blockIdx.x, + gridDim.x, ...) and the images of an item land under arithmetic that does not need them:
+//   top of item n:  [wait: Q / dO / O images of item n landed]  stage K / V (n)  -- they land under delta + phase 1, which take K and V of the
+//                   wave's own key tile from REGISTERS (fetched one item ahead) and read only the Q / dO images
+//   after phase 1:  the wave's own Q / dO fragments go to registers; barrier; stage Q / dO / O (n + 1) into the freed regions -- they land
+//                   under phase 2, which reads only the K / V images; [counted wait: K / V (n) landed]
+// Waits are COUNTED: the wait in the middle sits right after exactly 12 LDS-DMA instructions of this wave (three images x 4), so
+// `vmcnt(12)` means "everything issued before those twelve has landed" whatever else is in flight; outputs are stored after a wait,
+// never in front of one.  Barriers are raw s_barrier (a __syncthreads would drain the prefetch).
+// hipcc places `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 BUILTIN while any LDS-DMA is outstanding (it does not for plain
+// ds_read_b128), which would serialise exactly the overlap this kernel is built for: the transposed reads here are inline assembly
+// (eight reads and one lgkmcnt wait per statement).
+typedef __attribute__((address_space(3))) char* lds_cptr;
+__device__ __forceinline__ uint32_t lds_addr(const char* ptr) { return (uint32_t)(uintptr_t)(lds_cptr)(char*)ptr; }
+
+// four col_frag operands (eight transposed 8-byte reads) issued back to back, one wait; a[2 i], a[2 i + 1] = LDS byte addresses of operand i
+__device__ __forceinline__ void tr_read4(const uint32_t (&a)[8], bf16x8 (&f)[4]) {
+    unsigned long long r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                 "ds_read_b64_tr_b16 %1, %9\n\t"
+                 "ds_read_b64_tr_b16 %2, %10\n\t"
+                 "ds_read_b64_tr_b16 %3, %11\n\t"
+                 "ds_read_b64_tr_b16 %4, %12\n\t"
+                 "ds_read_b64_tr_b16 %5, %13\n\t"
+                 "ds_read_b64_tr_b16 %6, %14\n\t"
+                 "ds_read_b64_tr_b16 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+                 : "memory");
+    const unsigned long long r[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const s4 lo = __builtin_bit_cast(s4, r[2 * i]), hi = __builtin_bit_cast(s4, r[2 * i + 1]);
+        f[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+__device__ __forceinline__ void tr_read2(const uint32_t (&a)[4], bf16x8 (&f)[2]) {
+    unsigned long long r0, r1, r2, r3;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                 "ds_read_b64_tr_b16 %1, %5\n\t"
+                 "ds_read_b64_tr_b16 %2, %6\n\t"
+                 "ds_read_b64_tr_b16 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+                 : "memory");
+    const unsigned long long r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const s4 lo = __builtin_bit_cast(s4, r[2 * i]), hi = __builtin_bit_cast(s4, r[2 * i + 1]);
+        f[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams p, int n_items) {
+    REID_T16_ENTER();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = NT * 32 * 128;
+    char* Qs = smem;
+    char* Gs = smem + IMG;                           // dO
+    char* Os = smem + 2 * IMG;                       // O (delta only)
+    char* Ks = smem + 3 * IMG;
+    char* Vs = smem + 4 * IMG;
+    float* rowc = (float*)(smem + 5 * IMG);          // [2][NT*32]: -lse * log2(e), -delta / 8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = p.heads * 64;
+    const int t0 = wave * 32;
+    const int ti = t0 + (lane & 31);
+    const int trow = ti < p.S ? ti : p.S - 1;
+    const bool tile_ok = ti < p.S;
+    const float c = 0.125f * LOG2E;
+    const int h4 = 4 * (lane >> 5);
+    const FragOff fo = make_frag_off(lane);
+    const int nt = (p.S + 31) / 32;                  // == NT (launch_bwd picks NT = ceil(S / 32)): every wave owns a real tile
+    const uint32_t aQ = lds_addr(Qs), aG = lds_addr(Gs), aK = lds_addr(Ks);
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto item_ptrs = [&](int item, const bf16_t*& qb, const bf16_t*& gb, const bf16_t*& ob, size_t& so0) {
+        const int seq = item / p.heads, head = item % p.heads;
+        qb = p.qkv + (size_t)seq * p.S * p.ld + head * 64;
+        gb = p.dout + (size_t)seq * p.S * p.ldo + head * 64;
+        ob = p.out + (size_t)seq * p.S * p.ldo + head * 64;
+        so0 = ((size_t)seq * p.heads + head) * p.S;
+    };
+
+    int item = blockIdx.x;
+    const bf16_t *qb, *gb, *ob;
+    size_t so0;
+    item_ptrs(item, qb, gb, ob, so0);
+    // prologue: Q / dO / O images and the register operands of the first item
+    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane);
+    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane);
+    stage_head<NT>(ob, p.ldo, p.S, Os, wave, lane);
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = gfrag(qb + d, p.ld, trow, 2 * ks, lane);
+        vf[ks] = gfrag(qb + 2 * d, p.ld, trow, 2 * ks, lane);
+    }
+    float lse_v = p.lse[so0 + trow];
+    for (;;) {
+        // everything in flight has landed: this item's Q / dO / O images (staged under the previous item's phase 2) and register operands
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the compiler tracks the register operands itself and does not see the wait above: a use of each of them HERE makes it place its
+        //  own wait here, where nothing else is in flight, rather than behind the K / V staging below)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
+        asm volatile("" :: "v"(lse_v));
+        bar();                                       // ... for every wave; and nobody reads the previous item's K / V images any more
+        stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);          // this item's K / V images: they land under delta + phase 1
+        stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
+        // ---- delta of this wave's query rows -> LDS, with the saved log-sum-exp
+        {
+            float dsum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 gfk = row_frag_o(Gs, t0, ks, fo), ofk = row_frag_o(Os, t0, ks, fo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(bf16_to_f32((bf16_t)gfk[j]), bf16_to_f32((bf16_t)ofk[j]), dsum);
+            }
+            dsum += __shfl_xor(dsum, 32, 64);
+            if (lane < 32) {
+                rowc[ti] = tile_ok ? -lse_v * LOG2E : -INFINITY;
+                rowc[NT * 32 + ti] = tile_ok ? -dsum * 0.125f : 0.f;
+            }
+        }
+        bar();                                       // rowc complete
+        // ---- phase 1: this wave's key tile (K, V of the tile in registers; Q / dO images)
+        f32x16 dkt[2], dvt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dkt[dt][e] = 0.f; dvt[dt][e] = 0.f; }
+        {
+            auto scores = [&](int qt, f32x16& s, f32x16& dp) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag_o(Qs, qt * 32, ks, fo), kf[ks], s);
+                    dp = mfma32(row_frag_o(Gs, qt * 32, ks, fo), vf[ks], dp);
+                }
+            };
+            f32x16 s, dp, s_n, dp_n;
+            scores(0, s, dp);
+            for (int qt = 0; qt < nt; ++qt) {
+                if (qt + 1 < nt) scores(qt + 1, s_n, dp_n);          // next tile's matrix work first: it runs under this tile's exponentials
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf, df;
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int g = 2 * s2 + g2;
+                        const f32x4 nl = *(const f32x4*)(rowc + qt * 32 + 8 * g + h4);
+                        const f32x4 nd = *(const f32x4*)(rowc + NT * 32 + qt * 32 + 8 * g + h4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int e = 4 * g + j;
+                            const float pe = fast_exp2(fmaf(s[e], c, nl[j]));
+                            pf[4 * g2 + j] = (short)f32_to_bf16(pe);
+                            df[4 * g2 + j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd[j]));
+                        }
+                    }
+                    const uint32_t row_off = (uint32_t)(qt * 32 + 16 * s2) * 128u;
+                    const uint32_t ad[8] = {aG + row_off + fo.col_lo[0], aG + row_off + fo.col_hi[0], aG + row_off + fo.col_lo[1], aG + row_off + fo.col_hi[1],
+                                            aQ + row_off + fo.col_lo[0], aQ + row_off + fo.col_hi[0], aQ + row_off + fo.col_lo[1], aQ + row_off + fo.col_hi[1]};
+                    bf16x8 tf[4];
+                    tr_read4(ad, tf);
+                    dvt[0] = mfma32(tf[0], pf, dvt[0]);
+                    dvt[1] = mfma32(tf[1], pf, dvt[1]);
+                    dkt[0] = mfma32(tf[2], df, dkt[0]);
+                    dkt[1] = mfma32(tf[3], df, dkt[1]);
+                }
+                s = s_n; dp = dp_n;
+            }
+        }
+        // this wave's own query-tile fragments and row constants for phase 2: the last reads of the Q / dO images and of rowc
+        bf16x8 qf[4], gf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag_o(Qs, t0, ks, fo); gf[ks] = row_frag_o(Gs, t0, ks, fo); }
+        const float nl = rowc[ti], nd = rowc[NT * 32 + ti];
+        bf16_t* drow = p.dqkv + ((size_t)(item / p.heads) * p.S + trow) * p.lddqkv + (item % p.heads) * 64;
+        bar();                                       // nobody reads the Q / dO / O images (or rowc) of this item any more
+        const int nxt = item + (int)gridDim.x;
+        const bool has_next = nxt < n_items;         // (workgroup-uniform)
+        const bf16_t *qb_n = qb, *gb_n = gb, *ob_n = ob;
+        size_t so_n = so0;
+        if (has_next) item_ptrs(nxt, qb_n, gb_n, ob_n, so_n);
+        if (has_next) {
+            // the next item's Q / dO / O images into the freed regions: twelve DMA instructions per wave, then the counted wait
+            stage_head<NT>(qb_n, p.ld, p.S, Qs, wave, lane);
+            stage_head<NT>(gb_n, p.ldo, p.S, Gs, wave, lane);
+            stage_head<NT>(ob_n, p.ldo, p.S, Os, wave, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // everything older has landed: in particular this item's K / V images
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bar();                                       // ... for every wave
+        // (outputs of phase 1 are stored only now: a store in front of the wait would have to be acknowledged before it passes)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            store_tile_row16(drow + d + dt * 32, tile_ok, dkt[dt], 1.0f, lane);
+            store_tile_row16(drow + 2 * d + dt * 32, tile_ok, dvt[dt], 1.0f, lane);
+        }
+        // register operands of the next item (consumed at the top of the loop, behind its vmcnt(0); past the last item the pointers are
+        // the current item's: valid addresses, values unused)
+        bf16x8 kf_n[4], vf_n[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf_n[ks] = gfrag(qb_n + d, p.ld, trow, 2 * ks, lane);
+            vf_n[ks] = gfrag(qb_n + 2 * d, p.ld, trow, 2 * ks, lane);
+        }
+        const float lse_n = p.lse[so_n + trow];
+        // ---- phase 2: this wave's query tile (Q, dO of the tile in registers; K / V images)
+        f32x16 dqt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+        {
+            auto scores_t = [&](int kt, f32x16& s, f32x16& dp) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag_o(Ks, kt * 32, ks, fo), qf[ks], s);
+                    dp = mfma32(row_frag_o(Vs, kt * 32, ks, fo), gf[ks], dp);
+                }
+            };
+            f32x16 s, dp;
+            scores_t(0, s, dp);
+            for (int kt = 0; kt < nt; ++kt) {
+                if (kt > 0) scores_t(kt, s, dp);     // (not pipelined like phase 1: with the next item's operands in registers a second accumulator pair spills, and a scratch reload is a VMEM operation in the middle of the counted waits)
+                const bool edge = (kt + 1) * 32 > p.S;
+                bf16x8 df[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = 8 * s2 + j;
+                        float pe = fast_exp2(fmaf(s[e], c, nl));
+                        if (edge) {
+                            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + h4;
+                            pe = key < p.S ? pe : 0.f;
+                        }
+                        df[s2][j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd));
+                    }
+                const uint32_t r0 = (uint32_t)(kt * 32) * 128u, r1 = r0 + 16u * 128u;
+                const uint32_t ad[8] = {aK + r0 + fo.col_lo[0], aK + r0 + fo.col_hi[0], aK + r0 + fo.col_lo[1], aK + r0 + fo.col_hi[1],
+                                        aK + r1 + fo.col_lo[0], aK + r1 + fo.col_hi[0], aK + r1 + fo.col_lo[1], aK + r1 + fo.col_hi[1]};
+                bf16x8 tf[4];
+                tr_read4(ad, tf);
+                dqt[0] = mfma32(tf[0], df[0], dqt[0]);
+                dqt[1] = mfma32(tf[1], df[0], dqt[1]);
+                dqt[0] = mfma32(tf[2], df[1], dqt[0]);
+                dqt[1] = mfma32(tf[3], df[1], dqt[1]);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) store_tile_row16(drow + dt * 32, tile_ok, dqt[dt], 1.0f, lane);
+        if (!has_next) break;                        // (nothing of this wave is in flight towards LDS: the last DMA was waited for above)
+        item = nxt; qb = qb_n; gb = gb_n; ob = ob_n; so0 = so_n;
+        lse_v = lse_n;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kf_n[ks]; vf[ks] = vf_n[ks]; }
+    }
+}
+
 template <int NT>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * NT * 32 * 128;
@@ -499,6 +968,26 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS2 = 2 * NT * 32 * 128;
     REID_MAX_LDS((attn_bwd_dkv_kernel<NT>), LDS1);
     REID_MAX_LDS((attn_bwd_dq_kernel<NT>), LDS2);
+    // REID_ATTN_BWD: 1 = the two-kernel form, 2 = one pass, one item per workgroup, 3 = one pass, persistent; default: persistent when no
+    // query tile is pruned and there are at least two items per CU, else the one-item form.  Masked / causal attention: two kernels.
+    const int impl = reid_knob(KNOB_ATTN_BWD);
+    if (!p.key_mask && !p.causal && impl != 1) {
+        constexpr int LDSF = 4 * NT * 32 * 128 + 2 * NT * 32 * 4;
+        constexpr int LDSP = 5 * NT * 32 * 128 + 2 * NT * 32 * 4;          // + the O image
+        const int n_items = p.n_seq * p.heads;
+        const int cus = reid_num_cus();
+        const bool pers_ok = p.q_tiles <= 0 && (p.S + 31) / 32 == NT;
+        if (pers_ok && (impl == 3 || (impl <= 0 && n_items >= 2 * cus))) {
+            REID_MAX_LDS((attn_bwd_pers_kernel<NT>), LDSP);
+            hipLaunchKernelGGL(attn_bwd_pers_kernel<NT>, dim3(n_items < cus ? n_items : cus), dim3(NT * 64), LDSP, s, p, n_items);
+            REID_CHECK_LAUNCH("reid_attn_bwd(persistent)");
+            return REID_OK;
+        }
+        REID_MAX_LDS((attn_bwd_fused_kernel<NT>), LDSF);
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<NT>, dim3(n_items), dim3(NT * 64), LDSF, s, p);
+        REID_CHECK_LAUNCH("reid_attn_bwd(fused)");
+        return REID_OK;
+    }
     // dQ first: it also produces delta (rows of the query tiles that take part), which the dK/dV kernel reads
     hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3(p.n_seq * p.heads), dim3(NT * 64), LDS2, s, p);
     REID_CHECK_LAUNCH("reid_attn_bwd(dq)");

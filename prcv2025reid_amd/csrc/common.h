@@ -17,7 +17,8 @@ __attribute__((visibility("hidden"))) void reid_set_error(const char* fmt, ...);
 // environment (REID_<NAME>) on first use and changed afterwards only through reid_set_knob() -- no getenv() on the launch path.
 enum reid_knob_id {
     KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI, KNOB_GEMM_STAGGER,
-    KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_STREAM_GROUPS, KNOB_SDM_IMPL, KNOB_SKINNY_TILE, KNOB_GEMM_PERSIST, KNOB_COUNT
+    KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_STREAM_GROUPS, KNOB_SDM_IMPL, KNOB_SKINNY_TILE, KNOB_GEMM_PERSIST,
+    KNOB_ATTN_BWD, KNOB_LORA_IMPL, KNOB_GELU_IMPL, KNOB_HEAD_IMPL, KNOB_COUNT
 };
 // (internal C++ symbols of the library: hidden, only the extern "C" entry points of include/reid_hip.h are exported)
 __attribute__((visibility("hidden"))) int reid_knob(int id);
@@ -125,6 +126,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const pk_t16x2 r = __builtin_convertvector(pk_f32x2{lo, hi}, pk_t16x2);
     return __builtin_bit_cast(uint32_t, r);
 }
+
+// IEEE half whatever the flavor (REID_F16 tensors): round-to-nearest-even pair conversion (v_cvt_pk_f16_f32)
+typedef _Float16 pk_h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const pk_h16x2 r = __builtin_convertvector(pk_f32x2{lo, hi}, pk_h16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float f16_to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+// MODE.FP16_OVFL for the calling wave: conversions to half clamp finite overflow to +-65504 (what REID_T16_ENTER does in the f16 flavor)
+#define REID_F16_SATURATE() __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -54,7 +54,9 @@ struct GemmParams {
 // GELU2D / MULAUX (r02): the training path saves gelu'(u) in the forward epilogue -- it shares the erfc and exp of the value -- so
 // the backward epilogue is one multiply per element instead of ~23 VALU operations (epilogues of this family are VALU-bound at
 // two waves per SIMD: ~12 us per 256 x 256 tile, tools/exp_epilogue_scale.py).
-enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4, EPI_GELU2D = 5, EPI_MULAUX = 6 };
+// PLAIN16H (r04, bf16 flavor only): the plain 16-bit store in IEEE half (REID_F16 output) -- the residual-branch outputs (out-projection,
+// fc2) are consumed by the add + LayerNorm kernel, never by an MFMA, so they can carry half's 11 significant bits instead of bf16's 8.
+enum { EPI_GENERIC = 0, EPI_PLAIN16 = 1, EPI_RES32 = 2, EPI_GELU2 = 3, EPI_DGELU = 4, EPI_GELU2D = 5, EPI_MULAUX = 6, EPI_PLAIN16H = 7 };
 
 using namespace gemmcore;
 
@@ -359,7 +361,11 @@ __device__ __forceinline__ void store_tile_fast(const GemmParams& p, f32x4 (&acc
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= bf16_to_f32((bf16_t)av[i][pc][e]);
                 }
-                if (ok) st_out((uint4*)(C + co + 64u * pc), uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+                if constexpr (EPI == EPI_PLAIN16H) {
+                    if (ok) st_out((uint4*)(C + co + 64u * pc), uint4{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7])});
+                } else {
+                    if (ok) st_out((uint4*)(C + co + 64u * pc), uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+                }
             }
         }
     }
@@ -386,7 +392,7 @@ static int pick_epilogue(const GemmParams& p, int BN) {
         return EPI_GENERIC;
     }
     if (!p.perm_b || p.R || p.row_scale) return EPI_GENERIC;
-    if (p.act == REID_ACT_NONE && !p.C2 && !p.aux) return EPI_PLAIN16;
+    if (p.act == REID_ACT_NONE && !p.C2 && !p.aux) return p.c_dtype == REID_F16 ? EPI_PLAIN16H : EPI_PLAIN16;
     if (p.act == REID_ACT_GELU_ERF && p.C2 && p.c2_dtype != REID_F32 && !p.aux) return EPI_GELU2;
     if (p.act == REID_ACT_DGELU_ERF && p.aux && !p.C2) return EPI_DGELU;
     if (p.act == REID_ACT_GELU_ERF_DSAVE && p.C2 && p.c2_dtype != REID_F32 && !p.aux) return EPI_GELU2D;
@@ -411,6 +417,7 @@ template <int BM, int BN, int WM, int WN, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmParams p) {
     REID_T16_ENTER();
     using C = Cfg<BM, BN, WM, WN>;
+    if constexpr (EPI == EPI_PLAIN16H) REID_F16_SATURATE();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -447,6 +454,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mer_gemm_kernel(const GemmPara
 template <int EPI, int BM = 256>
 __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p) {
     REID_T16_ENTER();
+    if constexpr (EPI == EPI_PLAIN16H) REID_F16_SATURATE();
     using PC = PPCfg<BM, 256>;
     constexpr int TM = PC::TM, RW = PC::RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -541,6 +549,7 @@ extern "C" void reid_debug_gemm_trace(void* buf) { g_gemm_trace = (unsigned long
 template <int EPI, int BM = 256>
 __global__ __launch_bounds__(512, 2) void mer_gemm_pps_kernel(const GemmParams p) {
     REID_T16_ENTER();
+    if constexpr (EPI == EPI_PLAIN16H) REID_F16_SATURATE();
     using PC = PPCfg<BM, 256>;
     constexpr int TM = PC::TM, RW = PC::RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -640,7 +649,7 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
     // so the HBM-bound side-stream kernels cannot take compute units from it (q|k|v backward 263 -> 194 us in-step)
     const int pk = reid_knob(KNOB_GEMM_PERSIST) < 0 ? 9 : reid_knob(KNOB_GEMM_PERSIST);
     const bool persist = pk != 0 && p.K2 == 0 && p.K >= 192 && (reid_num_cus() & ~7) >= 8 &&
-                         (p.epi == EPI_PLAIN16 || p.epi == EPI_RES32 || ((pk & 2) && (p.epi == EPI_GELU2 || p.epi == EPI_GELU2D)) ||
+                         (p.epi == EPI_PLAIN16 || p.epi == EPI_PLAIN16H || p.epi == EPI_RES32 || ((pk & 2) && (p.epi == EPI_GELU2 || p.epi == EPI_GELU2D)) ||
                           ((pk & 4) && p.epi == EPI_MULAUX));
     // (r03, tools/bench_gemm_shapes.py, profiles/r03_gemm_pps2.log: q|k|v 195 -> 183 us, q|k|v backward 157 -> 151, fc1 backward 207 -> 202,
     //  residual shapes unchanged; the GELU shapes are 2 % SLOWER persistent (327 -> 334 us: their 6 + 3.5 us VALU-bound epilogue dominates the
@@ -649,6 +658,9 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
 #define REID_PPS_CASE(E) case E: return bm == 224 ? launch_pps_e<E, 224>(p, s) : launch_pps_e<E, 256>(p, s);
         switch (p.epi) {
             REID_PPS_CASE(EPI_PLAIN16)
+#ifndef REID_FLAVOR_F16
+            REID_PPS_CASE(EPI_PLAIN16H)
+#endif
             REID_PPS_CASE(EPI_RES32)
             REID_PPS_CASE(EPI_GELU2)
             REID_PPS_CASE(EPI_GELU2D)
@@ -660,6 +672,9 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
 #define REID_PP_CASE(E) case E: return bm == 224 ? launch_pp_e<E, 224>(p, s) : launch_pp_e<E, 256>(p, s);
     switch (p.epi) {
         REID_PP_CASE(EPI_PLAIN16)
+#ifndef REID_FLAVOR_F16
+        REID_PP_CASE(EPI_PLAIN16H)
+#endif
         REID_PP_CASE(EPI_RES32)
         REID_PP_CASE(EPI_GELU2)
         REID_PP_CASE(EPI_DGELU)
@@ -685,6 +700,9 @@ int launch_main(GemmParams& p, hipStream_t s) {
     p.epi = reid_knob(KNOB_GEMM_EPI) == 0 ? EPI_GENERIC : pick_epilogue(p, 128);
     switch (p.epi) {
         case EPI_PLAIN16: return launch_e<128, 128, 2, 2, EPI_PLAIN16>(p, s);
+#ifndef REID_FLAVOR_F16
+        case EPI_PLAIN16H: return launch_e<128, 128, 2, 2, EPI_PLAIN16H>(p, s);
+#endif
         case EPI_RES32: return launch_e<128, 128, 2, 2, EPI_RES32>(p, s);
         case EPI_GELU2: return launch_e<128, 128, 2, 2, EPI_GELU2>(p, s);
         case EPI_DGELU: return launch_e<128, 128, 2, 2, EPI_DGELU>(p, s);
@@ -772,12 +790,21 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
     p.c_group = a->c_group; p.c_group_stride = a->c_group_stride; p.c_row_off = a->c_row_off;
     p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
     p.dbg = 0;
+    if (p.c_dtype == REID_F16 && REID_FLAVOR_ID == 1) p.c_dtype = REID_BF16;          // the f16 flavor's own format (saturating there too)
+    REID_CHECK_ARG(!(a->C2 && a->c2_dtype == REID_F16 && REID_FLAVOR_ID == 0) && !(a->R && a->r_dtype == REID_F16 && REID_FLAVOR_ID == 0),
+                   "reid_mer_gemm: REID_F16 is supported for C only");
     // L2 group height of the tile order: 16 row tiles when the weight panel set is wide and K short (q|k|v, fc1: the whole
     // [N, K] weight no longer fits one XCD's L2 next to 8 activation tiles and was re-streamed per group; r01 sweep 4..64)
     p.group_m = (p.K + p.K2 <= 1024 && p.N >= 1536) ? 16 : 8;
     if (reid_knob(KNOB_GEMM_GROUPM) > 0) p.group_m = reid_knob(KNOB_GEMM_GROUPM);
     p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (p.c_dtype == REID_F16) {
+        // only the plain lean epilogue stores IEEE half in the bf16 flavor (what the residual-branch GEMMs of the vision blocks use)
+        REID_CHECK_ARG(a->N > 96 && a->N % 128 == 0 && reid_knob(KNOB_GEMM_EPI) != 0 && reid_knob(KNOB_GEMM_TILE) <= 0 &&
+                       pick_epilogue(p, 128) == EPI_PLAIN16H,
+                       "reid_mer_gemm: a REID_F16 output needs the plain 16-bit epilogue (N a multiple of 128, no activation / residual / second output / mask / row remap)");
+    }
     // skinny outputs (LoRA down-projections, N <= 96) use a tall tile so no MFMA work is spent on padding
     // (tall 256-row tiles leave a 50k-row problem with < 256 workgroups: 64-row tiles fill the chip; r01: a three-buffer ring
     //  with counted vmcnt -- twice the bytes in flight per workgroup -- changed the step time by < 0.1 %: not kept)

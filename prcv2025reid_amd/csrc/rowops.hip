@@ -20,7 +20,8 @@ extern "C" int reid_version(void) { return 200; }
 // ---------------------------------------------------------------- experiment knobs (common.h)
 static const char* const g_knob_names[] = {
     "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM", "GEMM_EPI", "GEMM_STAGGER",
-    "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "STREAM_GROUPS", "SDM_IMPL", "SKINNY_TILE", "GEMM_PERSIST"};
+    "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "STREAM_GROUPS", "SDM_IMPL", "SKINNY_TILE", "GEMM_PERSIST",
+    "ATTN_BWD", "LORA_IMPL", "GELU_IMPL", "HEAD_IMPL"};
 static_assert(sizeof(g_knob_names) / sizeof(g_knob_names[0]) == KNOB_COUNT, "one name per reid_knob_id");
 static int g_knobs[KNOB_COUNT];
 static bool knob_is_debug(int i) { return i == KNOB_GEMM_DBG || i == KNOB_ATTN_DBG || i == KNOB_TOPK_DBG; }
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // (all 256 workgroups reach their epilogues together: 117 MB per round, ~23 us at HBM speed -- the out-projection ran at 21 % of the
 // MFMA peak, r02 verdict); here the GEMM stores 2 bytes per element and this kernel, which streams x anyway, does the add.  Same
 // bytes in total (GEMM 1.5 + this 9 KB per row against 6 + 4.5), but all of them at streaming speed and none under an idle MFMA.
+// Y_HALF: y is IEEE half whatever the flavor (REID_F16: r04, the branch output is not an MFMA operand, so it carries 11 significant
+// bits instead of bf16's 8 in the bf16 flavor as well).
+template <bool Y_HALF>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
                                                          const float* __restrict__ row_scale, int rows_per_img,
                                                          float* __restrict__ xo, int ldxo, const float* __restrict__ gamma,
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
             const f32x4 a = *(const f32x4*)(xr + c * 4);
             const bf16x4 b = *(const bf16x4*)(yr + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = fmaf(sc, bf16_to_f32((bf16_t)b[e]), a[e]);
+            for (int e = 0; e < 4; ++e) v[i][e] = fmaf(sc, Y_HALF ? f16_to_f32((unsigned short)b[e]) : bf16_to_f32((bf16_t)b[e]), a[e]);
             *(f32x4*)(xo + (size_t)row * ldxo + c * 4) = v[i];
         } else {
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -396,7 +400,7 @@ extern "C" int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* ro
     return REID_OK;
 }
 
-extern "C" int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t ldy, const float* row_scale,
+extern "C" int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int32_t y_dtype, int32_t ldy, const float* row_scale,
                                       int32_t rows_per_img, float* x_out, int32_t ldxo, const float* gamma, const float* beta,
                                       void* h_bf16, int32_t ldh, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
                                       void* stream) {
@@ -405,8 +409,13 @@ extern "C" int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y
     REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_add_layernorm_fwd: cols=%d unsupported", cols);
     REID_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldxo % 4 == 0 && ldh % 4 == 0 && ldx >= cols && ldy >= cols && ldxo >= cols && ldh >= cols,
                    "reid_add_layernorm_fwd: ld");
-    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)y_bf16, ldy, row_scale,
-                       rows_per_img, x_out, ldxo, gamma, beta, (bf16_t*)h_bf16, ldh, mean, rstd, rows, cols, eps);
+    REID_CHECK_ARG(y_dtype == REID_BF16 || y_dtype == REID_F16, "reid_add_layernorm_fwd: y_dtype=%d (REID_BF16 = flavor format, or REID_F16)", y_dtype);
+    if (y_dtype == REID_F16 && REID_FLAVOR_ID == 0)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)y_bf16, ldy, row_scale,
+                           rows_per_img, x_out, ldxo, gamma, beta, (bf16_t*)h_bf16, ldh, mean, rstd, rows, cols, eps);
+    else
+        hipLaunchKernelGGL(add_ln_fwd_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16_t*)y_bf16, ldy, row_scale,
+                           rows_per_img, x_out, ldxo, gamma, beta, (bf16_t*)h_bf16, ldh, mean, rstd, rows, cols, eps);
     REID_CHECK_LAUNCH("reid_add_layernorm_fwd");
     return REID_OK;
 }

@@ -416,7 +416,10 @@ class Engine:
             if add_ln and not last:
                 yb = buf.get('yb')
                 if yb is None:
-                    yb = buf['yb'] = torch.empty(M, d, **b16)
+                    # branch output of the out-projection / fc2 GEMM: consumed by the add + LayerNorm kernel, never by an MFMA, so it
+                    # is IEEE half (11 significant bits, saturating) in BOTH flavors (r03 stored bf16 in the bf16 flavor: one more
+                    # 8-bit rounding per residual branch, bn_features/8 3.8e-3 -> 4.3e-3)
+                    yb = buf['yb'] = torch.empty(M, d, dtype=torch.float16, device=dev)
                 ops.gemm(oin, we(l, 'out'), yb, bias=P[lp + 'attn.out_proj.shared_linear.bias'], row_groups=rg)
                 ops.add_layernorm_fwd(xin, yb, xm, P[lp + 'ln2.weight'], P[lp + 'ln2.bias'], h2, mean2, rstd2, row_scale=sa, rows_per_img=rpi)
             else:

@@ -49,7 +49,7 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         a.N, a.K = B.shape[0], B.shape[1]
         a.ldb = B.stride(0)
     a.lda, a.ldc = A.stride(0), C_out.stride(0)
-    a.c_dtype = L.dt(C_out)
+    a.c_dtype = L.dt(C_out, allow_half=True)
     if A2 is not None:
         a.A2, a.B2 = ptr(A2), ptr(B2)
         a.K2 = K2 or B2.shape[1]
@@ -79,7 +79,7 @@ def gemm(A, B, C_out, *, A2=None, B2=None, K2=0, k2_group_n=0, bias=None, R=None
         flops = 2.0 * a.M * a.N * kk
         # compulsory bytes of the launch: both operands once, C once, plus every epilogue operand it must read or write
         # (residual R, saved pre-activation aux, second output C2) -- r01 left the last three out and overstated traffic / algorithmic
-        nbytes = 2.0 * (a.M * kk + a.N * kk) + a.M * a.N * (2 if a.c_dtype == BF16 else 4)
+        nbytes = 2.0 * (a.M * kk + a.N * kk) + a.M * a.N * (4 if a.c_dtype == F32 else 2)
         if R is not None:
             nbytes += (r_period if r_period > 0 else a.M) * a.N * (2 if a.r_dtype == BF16 else 4)
         if aux is not None:
@@ -110,7 +110,7 @@ def layernorm_fwd(x, gamma, beta, y_bf16=None, y_f32=None, mean=None, rstd=None,
 
 def add_layernorm_fwd(x, y, x_out, gamma, beta, h, mean=None, rstd=None, row_scale=None, rows_per_img=0, eps=1e-5):
     """x_out = x + row_scale[row // rows_per_img] * y;  h = LayerNorm(x_out) (16-bit);  see reid_add_layernorm_fwd."""
-    check(lib().reid_add_layernorm_fwd(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(row_scale), rows_per_img, ptr(x_out), x_out.stride(0),
+    check(lib().reid_add_layernorm_fwd(ptr(x), x.stride(0), ptr(y), L.dt(y, allow_half=True), y.stride(0), ptr(row_scale), rows_per_img, ptr(x_out), x_out.stride(0),
                                        ptr(gamma), ptr(beta), ptr(h), h.stride(0), ptr(mean), ptr(rstd), x.shape[0], x.shape[1],
                                        C.c_float(eps), stream_ptr()))
 

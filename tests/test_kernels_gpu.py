@@ -296,6 +296,49 @@ def test_add_layernorm(ops, rows, rpi, cols, scaled):
     assert torch.equal(x2, xo)
 
 
+@pytest.mark.parametrize('M,N,K,groups', [(197 * 8, 768, 768, True), (1000, 768, 3072, False), (64, 256, 768, False), (50432, 768, 768, True)])
+def test_branch_output_in_ieee_half_both_flavors(ops, M, N, K, groups):
+    """r04: the out-projection / fc2 GEMM stores its branch output as IEEE half (REID_F16) in BOTH flavors and the add + LayerNorm kernel
+    reads it as such: C = half(A W^T + b) against fp64 within half's rounding (2^-11 relative, where bf16 storage would give 2^-8),
+    finite overflow saturates to +-65504, and the fused add sees exactly those half values."""
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device='cuda', generator=g))
+    nW = 4 if groups else 1
+    W = bf(torch.randn(nW, N, K, device='cuda', generator=g) / math.sqrt(K))
+    bias = torch.randn(N, device='cuda', generator=g)
+    C = torch.empty(M, N, device='cuda', dtype=torch.float16)
+    if groups:
+        q = (M // 197) // 4 * 197 if M % 197 == 0 else M // 4
+        ends = [q, 2 * q, 3 * q, M]
+        ops.gemm(A, W, C, bias=bias, row_groups=(ends, [2, 0, 3, 1]))
+        want = torch.empty(M, N, device='cuda', dtype=torch.float64)
+        lo = 0
+        for e_, w_ in zip(ends, [2, 0, 3, 1]):
+            want[lo:e_] = A[lo:e_].double() @ W[w_].double().t() + bias.double(); lo = e_
+    else:
+        ops.gemm(A, W[0], C, bias=bias)
+        want = A.double() @ W[0].double().t() + bias.double()
+    err = (C.double() - want).abs()
+    tol = 2.0 ** -11 * want.abs() + 2.0 ** -24 + 1e-5 * want.abs().max()      # half rounding + fp32 accumulation noise
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # saturation: a bias far outside half's range comes out as +-65504, not inf
+    big = bias.clone(); big[0] = 1e6; big[1] = -1e6
+    ops.gemm(A[:64], W[0], C[:64], bias=big)
+    assert float(C[:64, 0].float().min()) == 65504.0 and float(C[:64, 1].float().max()) == -65504.0 and bool(torch.isfinite(C[:64].float()).all())
+    # consumed by the add + LayerNorm as half: x_out = x + C exactly
+    ops.gemm(A, W[0], C, bias=bias)
+    x = torch.randn(M, N, device='cuda', generator=g)
+    xo = torch.empty_like(x); h = torch.empty(M, N, device='cuda', dtype=T16())
+    gamma = torch.ones(N, device='cuda'); beta = torch.zeros(N, device='cuda')
+    ops.add_layernorm_fwd(x, C, xo, gamma, beta, h)
+    assert torch.equal(xo, x + C.float())
+    # an activation / second output with a half C is refused (only the plain store exists in this format)
+    from prcv2025reid_amd import _lib
+    if _lib.flavor() == 'bf16':
+        with pytest.raises(_lib.ReidHipError):
+            ops.gemm(A, W[0], C, bias=bias, act='gelu')
+
+
 def _attn_ref(qkv, n_seq, S, heads, causal, key_mask):
     d = heads * 64
     q, k, v = [t.view(n_seq, S, heads, 64).transpose(1, 2) for t in qkv.split(d, dim=1)]
@@ -334,6 +377,51 @@ def test_attention(ops, n_seq, S, heads, causal, masked):
     for i, nm in enumerate('qkv'):
         a = dqkv[:, i * d:(i + 1) * d].float(); b = qf.grad[:, i * d:(i + 1) * d]
         assert rel_err(a, b) < 3e-2, nm
+
+
+@pytest.mark.parametrize('n_seq,S,heads,q_tiles', [(48, 197, 12, 0), (3, 197, 12, 0), (70, 50, 8, 0), (9, 64, 4, 0), (40, 197, 12, 1), (300, 5, 2, 0)])
+def test_attention_backward_forms(ops, n_seq, S, heads, q_tiles):
+    """The three forms of the attention backward (REID_ATTN_BWD 1 = two kernels, 2 = one pass with one item per workgroup, 3 = one pass,
+    persistent workgroups with the next item's images staged under the current item's arithmetic) against each other and against fp32
+    autograd, on item counts below and above two per CU, tile counts 1..7, and with the query-tile limit of the pruned last block."""
+    from prcv2025reid_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(n_seq + S)
+    d = heads * 64
+    qkv = bf(torch.randn(n_seq * S, 3 * d, device='cuda', generator=g))
+    out = torch.empty(n_seq * S, d, device='cuda', dtype=T16())
+    lse = torch.empty(n_seq, heads, S, device='cuda')
+    ops.attn_fwd(qkv, out, lse, n_seq, S, heads, q_tiles=q_tiles)
+    dout = bf(torch.randn(n_seq * S, d, device='cuda', generator=g))
+    qrows = min(S, 32 * q_tiles) if q_tiles else S
+    if q_tiles:                                           # rows beyond the limit take no part: their cotangent and output are unused
+        keep = torch.zeros(n_seq, S, 1, device='cuda'); keep[:, :qrows] = 1
+        dout = bf(dout.float().view(n_seq, S, d) * keep).view(n_seq * S, d)
+    res = {}
+    for impl in (1, 2, 3):
+        _lib.check(_lib.lib().reid_set_knob(b'ATTN_BWD', impl))
+        try:
+            dqkv = torch.full((n_seq * S, 3 * d), float('nan'), device='cuda', dtype=T16())
+            delta = torch.empty(n_seq, heads, S, device='cuda')
+            ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, n_seq, S, heads, q_tiles=q_tiles)
+            torch.cuda.synchronize()
+            res[impl] = dqkv.float()
+        finally:
+            _lib.check(_lib.lib().reid_set_knob(b'ATTN_BWD', -1))
+    assert bool(torch.isfinite(res[2]).all()) and bool(torch.isfinite(res[3]).all())
+    # the one-pass forms run the same arithmetic in the same order per element as the two-kernel form (delta from the same products)
+    for impl in (2, 3):
+        assert rel_err(res[impl], res[1]) < 2e-3, impl
+    assert torch.equal(res[2], res[3]) or rel_err(res[3], res[2]) < 1e-6
+    qf = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(qf, n_seq, S, heads, False, None)
+    ref.backward(dout.float())
+    want = qf.grad
+    if q_tiles:
+        want = want.clone().view(n_seq, S, 3 * d)
+        want[:, qrows:, :d] = 0                           # dQ of the rows left out is exactly zero (their own softmax rows are not formed)
+        want = want.view(n_seq * S, 3 * d)
+    for i, nm in enumerate('qkv'):
+        assert rel_err(res[3][:, i * d:(i + 1) * d], want[:, i * d:(i + 1) * d]) < 3e-2, nm
 
 
 def test_patch_and_cls(ops):
