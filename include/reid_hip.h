@@ -315,7 +315,9 @@ int reid_cosine_topk_exact_slots(const float* Qf, const float* Gf, int32_t Nq, i
 /* The reference's one-query-at-a-time form (tools/eval_mm_protocol.py:401-455: sim = q @ G.T; argsort) for a handful of
  * queries: ONE pass over the fp32 gallery (Ng*D*4 bytes, HBM-bound) instead of the batched pipeline's launch chain.  Same
  * fp32 scores and the same (score desc, index asc) lists as reid_cosine_topk.  Allowed when reid_topk_stream_ok() returns 1
- * (Nq <= 4, k <= 32, D a multiple of 256 up to 1024).  ws: reid_topk_stream_ws_bytes(k). */
+ * (Nq <= 4, k <= 32, D a multiple of 256 up to 1024).  ws: reid_topk_stream_ws_bytes(k) bytes owned by this entry point: ZERO before the
+ * first call and not written by anyone else between calls (its last 256 bytes hold the arrival counter of the one-query form, in which
+ * the workgroup whose partial list arrives last merges all lists -- one launch per call; every call leaves the counter at zero). */
 int32_t reid_topk_stream_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k);
 int64_t reid_topk_stream_ws_bytes(int32_t k);
 int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t Nq, int32_t Ng, int32_t D, int32_t k,

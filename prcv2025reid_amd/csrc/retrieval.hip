@@ -565,10 +565,21 @@ __device__ __forceinline__ int wave_select_lds(const float* sc, const int32_t* i
     return real < k ? real : k;
 }
 
-template <int DJ, int STREAM_ROWS, int NQP>      // D = 256 * DJ; NQP = queries of the pass rounded up to 1, 2 or 4
+__host__ __device__ inline int merge_survivor_cap(int n, int k) { const int c = 16 * k * k + 64; return c < n ? c : n; }
+__device__ __forceinline__ void merge_lists_in_lds(const float* sc, const int32_t* ix, float* ssc, int32_t* six, int* lcnt, int groups, int k,
+                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_score, int tid, int lane);
+
+// FUSE (one query per pass): the workgroup whose lists arrive LAST merges them and writes the final top-k -- no second launch (r03: the
+// merge kernel was 10.8 us of a 77 us call).  Hand-off per MI355X_MICROARCH "Valid forms", first row of the sc1 table: every list entry is
+// stored and loaded with agent-scope relaxed atomics (global_store / global_load ... sc1: write-through, L1-bypassing), every storing wave
+// drains its stores (vmcnt(0)) before the workgroup barrier, ONE lane then adds to the arrival counter, and the workgroup that sees the
+// last ticket loads the lists behind a barrier that follows the returned add.  The counter is left at zero for the next call.
+template <int DJ, int STREAM_ROWS, int NQP, bool FUSE = false>      // D = 256 * DJ; NQP = queries of the pass rounded up to 1, 2 or 4
 __global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restrict__ Qf, const float* __restrict__ Gf, int Ng,
                                                           const int32_t* __restrict__ exq, const int32_t* __restrict__ exg, int nq,
-                                                          int k, float* __restrict__ part_score, int32_t* __restrict__ part_idx) {
+                                                          int k, float* __restrict__ part_score, int32_t* __restrict__ part_idx,
+                                                          int32_t* __restrict__ counter = nullptr, int32_t* __restrict__ out_idx = nullptr,
+                                                          float* __restrict__ out_score = nullptr) {
     constexpr int D = 256 * DJ;
     __shared__ float lsc[SQ][4][STREAM_K_MAX];
     __shared__ int32_t lix[SQ][4][STREAM_K_MAX];
@@ -671,13 +682,77 @@ __global__ __launch_bounds__(256) void stream_topk_kernel(const float* __restric
         LaneList e;
         const int real = wave_select_lds(&lsc[w][0][0], &lix[w][0][0], 4 * STREAM_K_MAX, k, lane, e);
         if (lane < k) {
-            part_score[((size_t)w * gridDim.x + blockIdx.x) * k + lane] = lane < real ? e.s : -INFINITY;
-            part_idx[((size_t)w * gridDim.x + blockIdx.x) * k + lane] = lane < real ? e.i : -1;
+            const size_t o = ((size_t)w * gridDim.x + blockIdx.x) * k + lane;
+            if constexpr (FUSE) {
+                __hip_atomic_store(part_score + o, lane < real ? e.s : -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part_idx + o, lane < real ? e.i : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                part_score[o] = lane < real ? e.s : -INFINITY;
+                part_idx[o] = lane < real ? e.i : -1;
+            }
         }
+    }
+    if constexpr (FUSE) {
+        extern __shared__ __attribute__((aligned(16))) char smm[];
+        __shared__ int last_flag, lcnt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's list entries have left for memory
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = ticket == (int)gridDim.x - 1;
+            lcnt = 0;
+        }
+        __syncthreads();                                              // (every wave loads behind the barrier that follows the returned add)
+        if (!last_flag) return;
+        const int groups = gridDim.x, n = groups * k, n4 = (n + 3) & ~3;
+        float* sc = (float*)smm;
+        int32_t* ix = (int32_t*)(sc + n4);
+        float* ssc = (float*)(ix + n4);
+        int32_t* six = (int32_t*)(ssc + merge_survivor_cap(n, k));
+        for (int i = tid; i < n; i += 256) {
+            sc[i] = __hip_atomic_load(part_score + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ix[i] = __hip_atomic_load(part_idx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call (stream-ordered)
+        __syncthreads();
+        merge_lists_in_lds(sc, ix, ssc, six, &lcnt, groups, k, out_idx, out_score, tid, lane);
     }
 }
 
-__host__ __device__ inline int merge_survivor_cap(int n, int k) { const int c = 16 * k * k + 64; return c < n ? c : n; }
+
+// (all entries in LDS: sc / ix [groups * k], lists sorted best-first; ssc / six: survivor region; *lcnt == 0 on entry; 256 threads)
+__device__ __forceinline__ void merge_lists_in_lds(const float* sc, const int32_t* ix, float* ssc, int32_t* six, int* lcnt, int groups, int k,
+                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_score, int tid, int lane) {
+    // every wave derives the bar for itself (no cross-wave exchange)
+    LaneList hb{-INFINITY, -1};
+    for (int g = lane; g < groups; g += 64) {
+        const float hs = sc[g * k]; const int hi = ix[g * k];
+        if (hi >= 0 && (hb.i < 0 || ranks_before(hs, hi, hb.s, hb.i))) hb = LaneList{hs, hi};
+    }
+    const int nh = lanelist_sort(hb, 64, lane);
+    float bar_s = -INFINITY; int bar_i = 0x7fffffff;                // fewer than k non-empty lanes: no bar
+    if (nh >= k) {
+        bar_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hb.s), k - 1));
+        bar_i = __builtin_amdgcn_readlane(hb.i, k - 1);
+    }
+    for (int g = tid; g < groups; g += 256) {
+        const float* ls = sc + g * k; const int32_t* li = ix + g * k;
+        for (int c = 0; c < k; ++c) {                               // lists are sorted: stop at the first entry behind the bar
+            const float s = ls[c]; const int gi = li[c];
+            if (gi < 0 || ranks_before(bar_s, bar_i, s, gi)) break;
+            const int pos = atomicAdd(lcnt, 1);
+            ssc[pos] = s; six[pos] = gi;
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    LaneList e;
+    const int real = wave_select_lds(ssc, six, *lcnt, k, lane, e);
+    if (lane < k) {
+        out_idx[lane] = lane < real ? e.i : -1;
+        out_score[lane] = lane < real ? e.s : -INFINITY;
+    }
+}
 
 // One workgroup per query merges the workgroups' lists, each sorted best-first.  ALL entries come into LDS with one round of
 // coalesced 16-byte loads (r01 walked the lists in global memory: head, then entry after entry, each a dependent L2 round trip --
@@ -711,35 +786,7 @@ __global__ __launch_bounds__(256) void stream_merge_lds_kernel(const float* __re
         for (int i = tid; i < n; i += 256) { sc[i] = ps[i]; ix[i] = pi[i]; }
     }
     __syncthreads();
-    // every wave derives the bar for itself (no cross-wave exchange)
-    LaneList hb{-INFINITY, -1};
-    for (int g = lane; g < groups; g += 64) {
-        const float hs = sc[g * k]; const int hi = ix[g * k];
-        if (hi >= 0 && (hb.i < 0 || ranks_before(hs, hi, hb.s, hb.i))) hb = LaneList{hs, hi};
-    }
-    const int nh = lanelist_sort(hb, 64, lane);
-    float bar_s = -INFINITY; int bar_i = 0x7fffffff;                // fewer than k non-empty lanes: no bar
-    if (nh >= k) {
-        bar_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hb.s), k - 1));
-        bar_i = __builtin_amdgcn_readlane(hb.i, k - 1);
-    }
-    for (int g = tid; g < groups; g += 256) {
-        const float* ls = sc + g * k; const int32_t* li = ix + g * k;
-        for (int c = 0; c < k; ++c) {                               // lists are sorted: stop at the first entry behind the bar
-            const float s = ls[c]; const int gi = li[c];
-            if (gi < 0 || ranks_before(bar_s, bar_i, s, gi)) break;
-            const int pos = atomicAdd(&lcnt, 1);
-            ssc[pos] = s; six[pos] = gi;
-        }
-    }
-    __syncthreads();
-    if (tid >= 64) return;
-    LaneList e;
-    const int real = wave_select_lds(ssc, six, lcnt, k, lane, e);
-    if (lane < k) {
-        out_idx[(size_t)q * k + lane] = lane < real ? e.i : -1;
-        out_score[(size_t)q * k + lane] = lane < real ? e.s : -INFINITY;
-    }
+    merge_lists_in_lds(sc, ix, ssc, six, &lcnt, groups, k, out_idx + (size_t)q * k, out_score + (size_t)q * k, tid, lane);
 }
 
 // One workgroup per query merges the workgroups' lists, each sorted best-first.  The k-th best of 64 list heads (the best head
@@ -910,7 +957,8 @@ int launch_select_fast(const float* Qf, const float* Gf, int D, const int32_t* e
 extern "C" int32_t reid_topk_stream_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k) {
     return Nq >= 1 && Nq <= SQ && k >= 1 && k <= STREAM_K_MAX && k <= Ng && D % 256 == 0 && D >= 256 && D <= 1024 && Ng >= 1;
 }
-extern "C" int64_t reid_topk_stream_ws_bytes(int32_t k) { return (int64_t)SQ * stream_groups(k) * k * 8; }
+// lists of SQ queries + 256 bytes for the arrival counter of the one-query form (zero before the first call; every call leaves it zero)
+extern "C" int64_t reid_topk_stream_ws_bytes(int32_t k) { return (int64_t)SQ * stream_groups(k) * k * 8 + 256; }
 
 /* Top-k of a few queries in ONE pass over the fp32 gallery (the reference's one-query-at-a-time form).  Same results as
  * reid_cosine_topk; allowed when reid_topk_stream_ok().  ws: reid_topk_stream_ws_bytes(k). */
@@ -939,8 +987,16 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
         const int32_t* eq = exclude_q ? exclude_q + q0 : nullptr;
         // gallery rows per wave and iteration (the loads of all rows are issued before the first dot): 4 rows = 8 KiB in flight per wave at D = 512
         const int rows_env = reid_knob(KNOB_STREAM_ROWS);
+        const int n_ent = groups * k;
+        const size_t lds_fast = (size_t)((n_ent + 3) & ~3) * 8 + (size_t)merge_survivor_cap(n_ent, k) * 8;
+        // one query and lists that fit the LDS next to a second resident workgroup: the last-arriving workgroup merges (no second launch)
+        const bool fuse = nq == 1 && lds_fast <= 72 * 1024 && reid_knob(KNOB_STREAM_GROUPS) != 0;
+        int32_t* counter = (int32_t*)((char*)ws + (size_t)SQ * stream_groups(k) * k * 8);
 #define REID_STREAM_LAUNCH1(DJ, R, P) hipLaunchKernelGGL((stream_topk_kernel<DJ, R, P>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
-#define REID_STREAM_LAUNCH(DJ, R) do { if (nq == 1) REID_STREAM_LAUNCH1(DJ, R, 1); else if (nq == 2) REID_STREAM_LAUNCH1(DJ, R, 2); else REID_STREAM_LAUNCH1(DJ, R, 4); } while (0)
+#define REID_STREAM_LAUNCHF(DJ, R) do { REID_MAX_LDS((stream_topk_kernel<DJ, R, 1, true>), 72 * 1024); \
+        hipLaunchKernelGGL((stream_topk_kernel<DJ, R, 1, true>), dim3(groups), dim3(256), lds_fast, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi, counter, \
+                           out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k); } while (0)
+#define REID_STREAM_LAUNCH(DJ, R) do { if (fuse) REID_STREAM_LAUNCHF(DJ, R); else if (nq == 1) REID_STREAM_LAUNCH1(DJ, R, 1); else if (nq == 2) REID_STREAM_LAUNCH1(DJ, R, 2); else REID_STREAM_LAUNCH1(DJ, R, 4); } while (0)
         switch (D / 256) {
             case 1: REID_STREAM_LAUNCH(1, 4); break;
             case 2: if (rows_env == 2) REID_STREAM_LAUNCH(2, 2); else if (rows_env == 8) REID_STREAM_LAUNCH(2, 8); else REID_STREAM_LAUNCH(2, 4); break;
@@ -948,10 +1004,10 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
             default: REID_STREAM_LAUNCH(4, 2); break;
         }
 #undef REID_STREAM_LAUNCH
+#undef REID_STREAM_LAUNCHF
 #undef REID_STREAM_LAUNCH1
         REID_CHECK_LAUNCH("reid_cosine_topk_stream(scan)");
-        const int n_ent = groups * k;
-        const size_t lds_fast = (size_t)((n_ent + 3) & ~3) * 8 + (size_t)merge_survivor_cap(n_ent, k) * 8;
+        if (fuse) continue;
         if (lds_fast <= 160 * 1024 - 64)
             hipLaunchKernelGGL(stream_merge_lds_kernel, dim3(nq), dim3(256), lds_fast, s, ps, pi, groups, k, out_idx + (size_t)q0 * k,
                                out_score + (size_t)q0 * k);

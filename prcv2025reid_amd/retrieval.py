@@ -30,6 +30,7 @@ class GalleryIndex:
         self.Gb = ops.to_t16(self.Gf)
         self.img_ids = None if img_ids is None else img_ids.to(self.Gf.device, torch.int32).contiguous()
         self._ws = None
+        self._ws_stream = None
         self._exact_scratch = None
         self._slots = None             # device list of flagged queries of the last large call: [count, ids...]
         # Large calls resolve candidate-list overflows (queries flagged idx[q, 0] = -2) on the device, without reading the flags back:
@@ -54,12 +55,12 @@ class GalleryIndex:
             stream = ops.topk_stream_ok(Nq, Ng, Qf.shape[1], k)
         if stream:
             # a handful of queries: one pass over the fp32 gallery (the reference's per-query form), no host sync
-            need = ops.topk_stream_ws_bytes(k)
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=Qf.device)
+            need = ops.topk_stream_ws_bytes(k)             # (its own buffer, zero-filled once: it holds the arrival counter of the fused merge)
+            if self._ws_stream is None or self._ws_stream.numel() != need:
+                self._ws_stream = torch.zeros(need, dtype=torch.uint8, device=Qf.device)
             idx = torch.empty(Nq, k, dtype=torch.int32, device=Qf.device)
             sc = torch.empty(Nq, k, dtype=torch.float32, device=Qf.device)
-            ops.cosine_topk_stream(Qf, self.Gf, k, self._ws, idx, sc, exclude_q=exq, exclude_g=exg)
+            ops.cosine_topk_stream(Qf, self.Gf, k, self._ws_stream, idx, sc, exclude_q=exq, exclude_g=exg)
             return idx, sc
         chunk = max(1, int(self.exact_scratch_bytes // (4 * Ng)))
         if Nq > chunk and Nq * Ng > (1 << 26):

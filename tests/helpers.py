@@ -94,3 +94,16 @@ def check_fingerprint(z, state):
 def maxdiff(a, b):
     a = torch.as_tensor(np.asarray(a)).double(); b = torch.as_tensor(np.asarray(b)).double()
     return float((a - b).abs().max())
+
+
+def reference_trainable_groups(tag='tiny_frozen'):
+    """The reference's optimiser groups after train.py:1418-1458 -- get_learnable_params() filtered to requires_grad -- from the
+    inventory the reference itself produced (tests/golden/learnable_params.json: names, learning rates, trainable flags)."""
+    import json
+    groups = json.load(open(os.path.join(GOLDEN, 'learnable_params.json')))[tag]
+    out = []
+    for g in groups:
+        keys = [k for k, t in zip(g['params'], g['trainable']) if t]
+        if keys:
+            out.append(dict(name=g['name'], lr=g['lr'], params=keys))
+    return out

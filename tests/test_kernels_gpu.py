@@ -697,6 +697,32 @@ def test_cosine_topk_stream_equals_batched_path(ops, Nq, Ng, D, k):
     assert torch.equal(i_d, i_s)
 
 
+def test_cosine_topk_one_query_fused_merge_repeated_calls(ops):
+    """One query at a time at the full gallery size: the last-arriving workgroup merges the partial lists inside the scan launch (r04).
+    Forty back-to-back calls on one index (the arrival counter must come back to zero every time), k changing in between, results equal
+    to the batched pipeline's bit for bit."""
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    g = torch.Generator(device='cuda').manual_seed(99)
+    Ng, D = 200000, 512
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(40, D, device='cuda', generator=g), dim=1)
+    G[77] = G[12345]; Q[3] = G[12345]
+    index = GalleryIndex(G, normalized=True)
+    want_i, want_s = index.topk(Q, k=10, normalized=True, stream=False)
+    got = [index.topk(Q[i:i + 1], k=10, normalized=True) for i in range(40)]          # no synchronisation in between
+    torch.cuda.synchronize()
+    for i, (gi, gs) in enumerate(got):
+        assert torch.equal(gi[0], want_i[i]) and torch.equal(gs[0], want_s[i]), i
+    assert got[3][0][0, :2].tolist() == [77, 12345]
+    w5_i, w5_s = index.topk(Q[:8], k=5, normalized=True, stream=False)
+    for i in range(8):
+        gi, gs = index.topk(Q[i:i + 1], k=5, normalized=True)
+        assert torch.equal(gi[0], w5_i[i]) and torch.equal(gs[0], w5_s[i])
+    gi, gs = index.topk(Q[:1], k=10, normalized=True)
+    assert torch.equal(gi[0], want_i[0])
+    assert int(index._ws_stream.view(torch.int32)[-64:].abs().sum()) == 0             # counter left at zero
+
+
 def test_small_head_kernels(ops):
     from oracle import reid_oracle as O
     from prcv2025reid_amd import head as H

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from helpers import GOLDEN, load_case, case_inputs
+from helpers import GOLDEN, load_case, case_inputs, reference_trainable_groups
 from oracle import step_oracle as so
 
 
@@ -14,7 +14,7 @@ def _setup(zero_b=False):
     cfg, arch, state, batch, tokens = case_inputs(meta)
     if zero_b:
         state = {k: (torch.zeros_like(v) if k.endswith('lora_B.weight') else v) for k, v in state.items()}
-    groups = json.load(open(os.path.join(GOLDEN, 'learnable_params.json')))['tiny_frozen']
+    groups = reference_trainable_groups('tiny_frozen')
     kw = dict(contrastive_weight=meta['contrastive_weight'], tau=meta['tau'], ce_weight=meta['ce_weight'])
     return state, arch, batch, tokens, groups, kw
 
@@ -28,6 +28,7 @@ def test_trajectory_oracle_first_loss_is_the_fixture_loss_and_steps_descend():
     assert losses[-1] < 0.7 * losses[0]
     moved = [k for k in t.keys if float((t.state[k].detach() - state[k]).abs().max()) > 0]
     assert all(k in moved for k in t.keys if '.loras.' in k) and 'bn_neck.classifier.weight' in moved and len(moved) >= 0.8 * len(t.keys)
+    assert all(('loras' in k or 'bn_neck' in k or 'null_tokens' in k) for k in t.keys)      # train.py:1421-1425
     frozen = [k for k in state if k not in t.keys and torch.is_tensor(state[k]) and state[k].dtype.is_floating_point and 'running' not in k and 'num_batches' not in k]
     assert all(torch.equal(t.state[k], state[k].float()) for k in frozen)
 

@@ -17,7 +17,7 @@ import os
 import pytest
 import torch
 
-from helpers import GOLDEN, load_case, case_inputs
+from helpers import GOLDEN, load_case, case_inputs, reference_trainable_groups
 from oracle import bounds
 from oracle import step_oracle as so
 
@@ -51,7 +51,7 @@ def test_training_trajectory_vs_oracle(flavor, init, regime):
     cfg, arch, state, batch, tokens = case_inputs(meta)
     if init == 'reference':                                   # mer_lora.py:37-38: lora_B = 0, the low-rank update starts at exactly 0
         state = {k: (torch.zeros_like(v) if k.endswith('lora_B.weight') else v) for k, v in state.items()}
-    groups = json.load(open(os.path.join(GOLDEN, 'learnable_params.json')))['tiny_frozen']
+    groups = reference_trainable_groups('tiny_frozen')
     scale = {'mer_loras': 50.0} if regime == 'adapters_x50' else 1.0
     kw = dict(contrastive_weight=meta['contrastive_weight'], tau=meta['tau'], ce_weight=meta['ce_weight'])
     labels = batch['person_id']
