@@ -416,6 +416,36 @@ def timed(step, steps, warmup, world, dev):
     return elapsed, L
 
 
+def head_section_ms(model, B, C, dev, reps=5):
+    """Time of the head section alone (model.head_section + compute_loss + their backward) on a batch of B samples: under data parallelism
+    every rank evaluates it on the GLOBAL batch (parallel.py), so this is the redundant work per rank that does not shrink with the world
+    size -- reported so that a scaling result below the target can be attributed."""
+    from collections import OrderedDict
+    g = torch.Generator(device=dev).manual_seed(5)
+    mods = list(model.arch['modalities'])
+    raw = OrderedDict((m, torch.randn(B, model.arch['fusion_dim'], device=dev, generator=g).requires_grad_(True)) for m in mods)
+    fmask = OrderedDict((m, torch.ones(B, device=dev)) for m in mods)
+    labels = (torch.arange(B, device=dev) // 4) % C
+    was = model.training
+    model.train()
+
+    def once():
+        out = model.head_section(raw, fmask)
+        L = model.compute_loss(out, labels)
+        gr = torch.autograd.grad(L['total_loss'], list(raw.values()), allow_unused=True)
+        return gr
+
+    for _ in range(2):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    model.train(was)
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
 def parity_check(local, rank_lora, C, P, K, flavors):
     """HIP (each flavor) vs the CPU oracle on the FULL-SIZE batch of the benchmarked workload, training forward with the random
     regularisers off (the oracle is deterministic): unit-normalised per-modality features and bn_features / 8, the three losses."""
@@ -572,6 +602,15 @@ def main():
                                'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
+    if rank == 0:
+        # the head section alone at this rank's batch and at the global batches of configs 3 / 5: under DP every rank runs it on the GLOBAL
+        # batch, so (head at world * B) - (head at B) is per-rank work that data parallelism adds
+        try:
+            hs = {str(b): head_section_ms(model, b, C, dev) for b in sorted({B, world * B, 8 * 128})}
+            res['head_section_ms'] = {'by_batch': hs, 'local_batch': B, 'global_batch': world * B,
+                                      'what': 'head_section + compute_loss + backward to the encoder features, wall time per call, this GPU alone'}
+        except Exception as e:                              # (attribution only: never fail the bench line on it)
+            res['head_section_ms'] = {'error': repr(e)}
     if world > 1:
         # single-GPU value of the SAME per-GPU workload, rank 0 alone (the others wait): what the N-GPU value is to be divided by
         dist.barrier()

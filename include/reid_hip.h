@@ -197,7 +197,10 @@ int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table,
  * Rp must be 32.  A wider cotangent (fc1: 3072 columns) is handled as column blocks of 768, one launch each on the same stream:
  * u_mode bit 0 = add the fp32 partial sums u_partial [M, 32] of the earlier blocks to this block's, bit 1 = store the sum to
  * u_partial instead of finishing U (mask, scale, 16-bit); the last block has bit 1 clear.  u_mode = 0: a 768-column linear, u_partial unused.
- * Other shapes: reid_mer_gemm (U) + reid_gemm_tn (dB). */
+ * Other shapes: reid_mer_gemm (U) + reid_gemm_tn (dB).
+ * T must be modality-masked (T[m, c] = 0 unless c / mask_r == img_mod[m / rows_per_img]) -- it is how reid_mer_gemm's mask epilogue
+ * produces it: with rows_per_img >= 32 and mask_r a divisor of 16 one workgroup streams one image (one modality) and touches only the
+ * aligned 16-column group of adapter columns that holds the modality's; elsewhere dB stays as it was. */
 int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U, int32_t ldu,
                         float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t N,
                         int32_t Rp, float scale, float* u_partial, int32_t u_mode, void* stream);

@@ -494,9 +494,17 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_dq_kernel(const AttnParams p
 // In-wave pipelining: the S / dP MFMAs of tile t + 1 are issued BEFORE the exponentials of tile t (two accumulator sets), so that
 // a wave's matrix work does not wait behind its own exp -> pack -> MFMA chain (r03: with one workgroup per CU that chain is exposed).
 // No key mask / causal form: the text tower's backward (rare: freeze_text_backbone=False) keeps the two-kernel path.
+#ifdef REID_ATTN_TRACE
+// experiment builds (tools/exp_attn_bwd_trace.py): s_memrealtime stamps of wave 0 / lane 0 of every workgroup at the phase boundaries
+__device__ unsigned long long* g_attn_bwd_trace = nullptr;
+#define ATTN_BWD_STAMP(slot) do { if (g_attn_bwd_trace && threadIdx.x == 0) g_attn_bwd_trace[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATTN_BWD_STAMP(slot) do { } while (0)
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParams p) {
     REID_T16_ENTER();
+    ATTN_BWD_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IMG = NT * 32 * 128;
     char* Qs = smem;
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParam
     const float lse_v = p.lse[so];
     const FragOff fo = make_frag_off(lane);
     __syncthreads();                                 // vmcnt(0) + barrier: the images are in LDS
+    ATTN_BWD_STAMP(1);
     {
         float dsum = 0.f;
         if (own_q) {
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParam
         }
     }
     __syncthreads();
+    ATTN_BWD_STAMP(2);
     if (t0 >= p.S) return;                           // (wave-uniform; no barrier follows)
     const float c = 0.125f * LOG2E;
     const int h4 = 4 * (lane >> 5);
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParam
             }
             s = s_n; dp = dp_n;
         }
+        ATTN_BWD_STAMP(3);
         bf16_t* drow = p.dqkv + ((size_t)seq * p.S + trow) * p.lddqkv + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -612,6 +623,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParam
     }
 
     // ------------------------------------------------------------------ phase 2: this wave's query tile
+    ATTN_BWD_STAMP(4);
     bf16_t* qrow_out = p.dqkv + ((size_t)seq * p.S + trow) * p.lddqkv + head * 64;
     if (!own_q) {                                    // query tile left out by q_tiles: its dQ rows are exactly zero
         if (tile_ok) {
@@ -665,8 +677,10 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const AttnParam
             }
             s = s_n; dp = dp_n;
         }
+        ATTN_BWD_STAMP(5);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) store_tile_row16(qrow_out + dt * 32, tile_ok, dqt[dt], 1.0f, lane);
+        ATTN_BWD_STAMP(6);
     }
 }
 
@@ -727,6 +741,23 @@ __device__ __forceinline__ void tr_read2(const uint32_t (&a)[4], bf16x8 (&f)[2])
     }
 }
 
+// stage_head with the LDS-DMA issued from inline assembly: hipcc then has NO vector-memory operation of this kernel's prefetch in its
+// scoreboard and leaves the LDS reads of the phases alone (with the builtin it puts `s_waitcnt vmcnt(0)` in front of every transposed
+// read while a DMA is outstanding).  M0 = LDS base of the wave-instruction; nothing else in the persistent kernel uses M0 (no builtin DMA).
+template <int NT>
+__device__ __forceinline__ void stage_head_asm(const bf16_t* __restrict__ base, int ld, int S, uint32_t lds_base, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rblk = (i * NT + wave) * 8;
+        const int row = rblk + (lane >> 3);
+        const int c = swz(row, lane & 7);
+        const int grow = row < S ? row : S - 1;
+        const bf16_t* src = base + (size_t)grow * ld + c * 8;
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)rblk * 128u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams p, int n_items) {
     REID_T16_ENTER();
@@ -749,7 +780,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
     const int h4 = 4 * (lane >> 5);
     const FragOff fo = make_frag_off(lane);
     const int nt = (p.S + 31) / 32;                  // == NT (launch_bwd picks NT = ceil(S / 32)): every wave owns a real tile
-    const uint32_t aQ = lds_addr(Qs), aG = lds_addr(Gs), aK = lds_addr(Ks);
+    const uint32_t aQ = lds_addr(Qs), aG = lds_addr(Gs), aO = lds_addr(Os), aK = lds_addr(Ks), aV = lds_addr(Vs);
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -769,9 +800,9 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
     size_t so0;
     item_ptrs(item, qb, gb, ob, so0);
     // prologue: Q / dO / O images and the register operands of the first item
-    stage_head<NT>(qb, p.ld, p.S, Qs, wave, lane);
-    stage_head<NT>(gb, p.ldo, p.S, Gs, wave, lane);
-    stage_head<NT>(ob, p.ldo, p.S, Os, wave, lane);
+    stage_head_asm<NT>(qb, p.ld, p.S, aQ, wave, lane);
+    stage_head_asm<NT>(gb, p.ldo, p.S, aG, wave, lane);
+    stage_head_asm<NT>(ob, p.ldo, p.S, aO, wave, lane);
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -779,7 +810,13 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
         vf[ks] = gfrag(qb + 2 * d, p.ld, trow, 2 * ks, lane);
     }
     float lse_v = p.lse[so0 + trow];
+#ifdef REID_ATTN_TRACE
+#define PSTAMP(slot) do { if (g_attn_bwd_trace && threadIdx.x == 0) g_attn_bwd_trace[(size_t)item * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
     for (;;) {
+        PSTAMP(0);
         // everything in flight has landed: this item's Q / dO / O images (staged under the previous item's phase 2) and register operands
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -789,8 +826,9 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
         for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(kf[ks]), "v"(vf[ks]));
         asm volatile("" :: "v"(lse_v));
         bar();                                       // ... for every wave; and nobody reads the previous item's K / V images any more
-        stage_head<NT>(qb + d, p.ld, p.S, Ks, wave, lane);          // this item's K / V images: they land under delta + phase 1
-        stage_head<NT>(qb + 2 * d, p.ld, p.S, Vs, wave, lane);
+        PSTAMP(1);
+        stage_head_asm<NT>(qb + d, p.ld, p.S, aK, wave, lane);          // this item's K / V images: they land under delta + phase 1
+        stage_head_asm<NT>(qb + 2 * d, p.ld, p.S, aV, wave, lane);
         // ---- delta of this wave's query rows -> LDS, with the saved log-sum-exp
         {
             float dsum = 0.f;
@@ -807,6 +845,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
             }
         }
         bar();                                       // rowc complete
+        PSTAMP(2);
         // ---- phase 1: this wave's key tile (K, V of the tile in registers; Q / dO images)
         f32x16 dkt[2], dvt[2];
 #pragma unroll
@@ -843,19 +882,16 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
                             df[4 * g2 + j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd[j]));
                         }
                     }
-                    const uint32_t row_off = (uint32_t)(qt * 32 + 16 * s2) * 128u;
-                    const uint32_t ad[8] = {aG + row_off + fo.col_lo[0], aG + row_off + fo.col_hi[0], aG + row_off + fo.col_lo[1], aG + row_off + fo.col_hi[1],
-                                            aQ + row_off + fo.col_lo[0], aQ + row_off + fo.col_hi[0], aQ + row_off + fo.col_lo[1], aQ + row_off + fo.col_hi[1]};
-                    bf16x8 tf[4];
-                    tr_read4(ad, tf);
-                    dvt[0] = mfma32(tf[0], pf, dvt[0]);
-                    dvt[1] = mfma32(tf[1], pf, dvt[1]);
-                    dkt[0] = mfma32(tf[2], df, dkt[0]);
-                    dkt[1] = mfma32(tf[3], df, dkt[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dvt[dt] = mfma32(col_frag_o(Gs, qt * 32 + 16 * s2, dt, fo), pf, dvt[dt]);
+                        dkt[dt] = mfma32(col_frag_o(Qs, qt * 32 + 16 * s2, dt, fo), df, dkt[dt]);
+                    }
                 }
                 s = s_n; dp = dp_n;
             }
         }
+        PSTAMP(3);
         // this wave's own query-tile fragments and row constants for phase 2: the last reads of the Q / dO images and of rowc
         bf16x8 qf[4], gf[4];
 #pragma unroll
@@ -870,9 +906,9 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
         if (has_next) item_ptrs(nxt, qb_n, gb_n, ob_n, so_n);
         if (has_next) {
             // the next item's Q / dO / O images into the freed regions: twelve DMA instructions per wave, then the counted wait
-            stage_head<NT>(qb_n, p.ld, p.S, Qs, wave, lane);
-            stage_head<NT>(gb_n, p.ldo, p.S, Gs, wave, lane);
-            stage_head<NT>(ob_n, p.ldo, p.S, Os, wave, lane);
+            stage_head_asm<NT>(qb_n, p.ld, p.S, aQ, wave, lane);
+            stage_head_asm<NT>(gb_n, p.ldo, p.S, aG, wave, lane);
+            stage_head_asm<NT>(ob_n, p.ldo, p.S, aO, wave, lane);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // everything older has landed: in particular this item's K / V images
             __builtin_amdgcn_sched_barrier(0);
@@ -882,21 +918,14 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
             __builtin_amdgcn_sched_barrier(0);
         }
         bar();                                       // ... for every wave
+        PSTAMP(4);
         // (outputs of phase 1 are stored only now: a store in front of the wait would have to be acknowledged before it passes)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             store_tile_row16(drow + d + dt * 32, tile_ok, dkt[dt], 1.0f, lane);
             store_tile_row16(drow + 2 * d + dt * 32, tile_ok, dvt[dt], 1.0f, lane);
         }
-        // register operands of the next item (consumed at the top of the loop, behind its vmcnt(0); past the last item the pointers are
-        // the current item's: valid addresses, values unused)
-        bf16x8 kf_n[4], vf_n[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf_n[ks] = gfrag(qb_n + d, p.ld, trow, 2 * ks, lane);
-            vf_n[ks] = gfrag(qb_n + 2 * d, p.ld, trow, 2 * ks, lane);
-        }
-        const float lse_n = p.lse[so_n + trow];
+        PSTAMP(5);
         // ---- phase 2: this wave's query tile (Q, dO of the tile in registers; K / V images)
         f32x16 dqt[2];
 #pragma unroll
@@ -931,20 +960,27 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_pers_kernel(const AttnParams
                         }
                         df[s2][j] = (short)f32_to_bf16(pe * fmaf(dp[e], 0.125f, nd));
                     }
-                const uint32_t r0 = (uint32_t)(kt * 32) * 128u, r1 = r0 + 16u * 128u;
-                const uint32_t ad[8] = {aK + r0 + fo.col_lo[0], aK + r0 + fo.col_hi[0], aK + r0 + fo.col_lo[1], aK + r0 + fo.col_hi[1],
-                                        aK + r1 + fo.col_lo[0], aK + r1 + fo.col_hi[0], aK + r1 + fo.col_lo[1], aK + r1 + fo.col_hi[1]};
-                bf16x8 tf[4];
-                tr_read4(ad, tf);
-                dqt[0] = mfma32(tf[0], df[0], dqt[0]);
-                dqt[1] = mfma32(tf[1], df[0], dqt[1]);
-                dqt[0] = mfma32(tf[2], df[1], dqt[0]);
-                dqt[1] = mfma32(tf[3], df[1], dqt[1]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dqt[dt] = mfma32(col_frag_o(Ks, kt * 32 + 16 * s2, dt, fo), df[s2], dqt[dt]);
             }
         }
+        PSTAMP(6);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) store_tile_row16(drow + dt * 32, tile_ok, dqt[dt], 1.0f, lane);
-        if (!has_next) break;                        // (nothing of this wave is in flight towards LDS: the last DMA was waited for above)
+        PSTAMP(7);
+        if (!has_next) break;
+        // register operands of the next item: K and V rows of this wave's key tile and the saved log-sum-exp.  Fetched HERE, after the
+        // phases (the compiler tracks these loads and would make every transposed LDS read of a phase wait for them); they are waited for
+        // at the top of the loop together with the dQ stores above (~1 us, the only exposed memory latency of an item)
+        bf16x8 kf_n[4], vf_n[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf_n[ks] = gfrag(qb_n + d, p.ld, trow, 2 * ks, lane);
+            vf_n[ks] = gfrag(qb_n + 2 * d, p.ld, trow, 2 * ks, lane);
+        }
+        const float lse_n = p.lse[so_n + trow];                        // (nothing of this wave is in flight towards LDS: the last DMA was waited for above)
         item = nxt; qb = qb_n; gb = gb_n; ob = ob_n; so0 = so_n;
         lse_v = lse_n;
 #pragma unroll
@@ -1004,6 +1040,13 @@ int check_common(const char* name, const void* qkv, int ld, int n_seq, int S, in
 }
 
 }  // namespace
+
+#ifdef REID_ATTN_TRACE
+extern "C" void reid_debug_attn_bwd_trace(void* buf) {
+    unsigned long long* ptr = (unsigned long long*)buf;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_bwd_trace), &ptr, sizeof(ptr));
+}
+#endif
 
 #define DISPATCH_NT(nt, fn, ...)                \
     switch (nt) {                               \

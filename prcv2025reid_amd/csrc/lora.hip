@@ -270,6 +270,147 @@ __global__ __launch_bounds__(NW * 64, 2) void lora_bwd_fused_kernel(const Params
 }
 }  // namespace fused
 
+// ---------------------------------------------------------------- r04: one IMAGE per workgroup, compact adapters, LDS-DMA staging
+// The slab kernel above lasts 54 us alone (64 workgroups x 25 steps, two barriers and an 8-way LDS reduction per step, operands staged
+// through 56 VGPRs) and ~125 us inside the training step, where every microsecond of a side-stream kernel is a microsecond a persistent
+// GEMM workgroup starts late.  This form is bound by the HBM stream and nothing else, on EVERY CU at once:
+//   * a workgroup owns one image (rows_per_img rows: one modality mu), so only a 16-column WINDOW of the adapter columns (the r columns of
+//     mu and their neighbours inside an aligned group of 16) takes part: dB is [768, 16] per workgroup = 8 accumulator tiles in six waves
+//     (flush: 768 x r fp32 atomics per image instead of 768 x 32 per slab), U is two 16 x 16 tiles per 32-row step;
+//   * the dY tile of a step (32 rows x 768 columns, 48 KiB) and the T tile land by LDS-DMA in a source-swizzled image (no staging
+//     registers); two buffers, ONE barrier per step; waves 0-1 form U (each a whole K = 768 contraction: no cross-wave reduction), waves
+//     2-7 form dB from transposed reads of the same image.
+// Contract difference to the slab kernel: T must be modality-masked (zero outside the columns of the row's modality), which is how the
+// forward produces it -- columns outside the window are neither read nor accumulated.
+namespace image {
+constexpr int N = fused::N, RP = fused::RP, R = 32;
+constexpr int ROW_BYTES = N * 2;                           // 1536: 96 chunks of 16 bytes
+constexpr int IMG_BYTES = R * ROW_BYTES;                   // 48 KiB
+constexpr int T_BYTES = R * RP * 2;                        // 2 KiB
+constexpr int BUF_BYTES = IMG_BYTES + T_BYTES;
+constexpr int LDS_BYTES = 2 * BUF_BYTES;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+using fused::s4; using fused::lds_s4_ptr; using fused::Params;
+
+// transposed operand from the swizzled image: 16 MFMA rows = image columns col0 .. col0 + 15, k = image rows 0 .. 31
+__device__ __forceinline__ bf16x8 tr_frag_swz(const char* img, int col0, int lane) {
+    const int l16 = lane & 15, fq = lane >> 4;
+    const int q = l16 >> 2, pp = l16 & 3;
+    const int col = col0 + 4 * pp;
+    const int r0 = 4 * fq + q, r1 = r0 + 16;
+    const char* a0 = img + r0 * ROW_BYTES + (((col >> 3) ^ (r0 & 15)) << 4) + (col & 7) * 2;
+    const char* a1 = img + r1 * ROW_BYTES + (((col >> 3) ^ (r1 & 15)) << 4) + (col & 7) * 2;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)a0);
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)a1);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void lora_bwd_image_kernel(const Params p) {
+    REID_T16_ENTER();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, fq = lane >> 4;
+    const int img = blockIdx.x;
+    const int rbeg = img * p.rows_per_img;
+    const int rend = min(p.M, rbeg + p.rows_per_img);
+    if (rbeg >= rend) return;                                 // (whole workgroup)
+    const int mu = p.img_mod[img];
+    const int w0 = (mu * p.mask_r) & ~15;                     // first adapter column of the 16-column window
+    const int c_lo = mu * p.mask_r - w0, c_hi = c_lo + p.mask_r;   // this modality's columns inside the window
+    const int steps = (rend - rbeg + R - 1) / R;
+
+    // one step's operands -> LDS: 48 dY instructions (eight waves x six) + two T instructions (waves 0, 1)
+    auto issue = [&](int t, int buf) {
+        char* base = smem + buf * BUF_BYTES;
+        const int r0 = rbeg + t * R;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int qd = w * 6 + j;                         // wave-instruction: linear chunks [64 qd, 64 qd + 64)
+            const int g = qd * 64 + lane;
+            const int row = g / 96, c = g - row * 96;
+            int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
+            const bf16_t* src = p.dY + (size_t)gr * p.lddy + ((c ^ (row & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + qd * 1024), 16, 0, 0);
+        }
+        if (w < 2) {
+            const int g = w * 64 + lane;                      // T tile: 32 rows x 4 chunks, lane-linear
+            const int row = g >> 2, c = g & 3;
+            int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.T + (size_t)gr * p.ldt + c * 8), (lptr_t)(base + IMG_BYTES + w * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    // B^T fragments of the window (waves 0, 1: B operand of U = dY . B: n = adapter column w0 + l16, k = dY column)
+    bf16x8 bfr[24];
+    if (w < 2) {
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) bfr[ks] = *(const bf16x8*)(p.BT + (size_t)(w0 + l16) * p.ldbt + ks * 32 + 8 * fq);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < steps; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of step t has landed (and its U stores of step t - 1 are out)
+        __syncthreads();                                      // ... everybody's; and everybody is done reading the other buffer (step t - 1)
+        if (t + 1 < steps) issue(t + 1, buf ^ 1);
+        const char* xs = smem + buf * BUF_BYTES;
+        const char* ts = xs + IMG_BYTES;
+        const int r0 = rbeg + t * R;
+        if (w < 2) {
+            // U[16 rows of this wave x 16 window columns]: the whole K = 768 contraction in this wave
+            f32x4 ua = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = 16 * w + l16;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) {
+                const bf16x8 af = *(const bf16x8*)(xs + row * ROW_BYTES + (((4 * ks + fq) ^ (row & 15)) << 4));
+                ua = mfma16(af, bfr[ks], ua);
+            }
+            // lane: column n = l16 of the window, rows 4 fq + e
+            const bool mine = l16 >= c_lo && l16 < c_hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = r0 + 16 * w + 4 * fq + e;
+                if (m >= rend) continue;
+                float v = ua[e];
+                if (p.u_mode & 1) v += p.Up[(size_t)m * RP + w0 + l16];
+                if (p.u_mode & 2) {
+                    p.Up[(size_t)m * RP + w0 + l16] = v;
+                } else {
+                    p.U[(size_t)m * p.ldu + w0 + l16] = f32_to_bf16(mine ? v * p.scale : 0.f);
+                    p.U[(size_t)m * p.ldu + (w0 ^ 16) + l16] = f32_to_bf16(0.f);      // the other half of the 32 adapter columns: other modalities
+                }
+            }
+        } else {
+            // dB[128 columns of this wave, window] += dY^T . T over the rows of this step (rows beyond the image: T fragment zeroed)
+            bf16x8 tf = fused::tr_frag(ts, RP * 2, 0, w0, lane);
+            const int nvalid = rend - r0;                     // >= 32 except in the last step
+            if (nvalid < R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                 // element j of lane-quarter fq: image row 16 (j >> 2) + 4 fq + (j & 3) (tr_frag)
+                    if (16 * (j >> 2) + 4 * fq + (j & 3) >= nvalid) tf[j] = 0;
+                }
+            }
+            const int cbase = (w - 2) * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = mfma16(tr_frag_swz(xs, cbase + i * 16, lane), tf, acc[i]);
+        }
+    }
+    if (w >= 2) {
+        // acc[i]: rows = dY columns cbase + 16 i + 4 fq + e, column = window column l16; only this modality's columns carry anything
+        if (l16 >= c_lo && l16 < c_hi) {
+            const int cbase = (w - 2) * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(p.dB + (size_t)(cbase + i * 16 + 4 * fq + e) * p.lddb + w0 + l16, acc[i][e]);
+        }
+    }
+}
+}  // namespace image
+
 }  // namespace
 
 extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U,
@@ -284,6 +425,14 @@ extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, 
     REID_CHECK_ARG(((uintptr_t)dY | (uintptr_t)T | (uintptr_t)BT) % 16 == 0 && (uintptr_t)U % 4 == 0, "reid_lora_bwd_fused: operand alignment");
     fused::Params p{(const bf16_t*)dY, (const bf16_t*)T, (const bf16_t*)BT, (bf16_t*)U, dB, img_mod, lddy, ldt, ldbt, ldu, lddb, rows_per_img,
                     mask_r, M, 0, scale, u_partial, u_mode};
+    // REID_LORA_IMPL: 1 = the slab kernel always; default: one image per workgroup where an image spans at least one 32-row step
+    if (reid_knob(KNOB_LORA_IMPL) != 1 && rows_per_img >= image::R && mask_r <= 16 && 16 % mask_r == 0) {
+        REID_MAX_LDS((image::lora_bwd_image_kernel), image::LDS_BYTES);
+        const int n_img = (M + rows_per_img - 1) / rows_per_img;
+        hipLaunchKernelGGL(image::lora_bwd_image_kernel, dim3(n_img), dim3(512), image::LDS_BYTES, (hipStream_t)stream, p);
+        REID_CHECK_LAUNCH("reid_lora_bwd_fused(image)");
+        return REID_OK;
+    }
     // few, long slabs: each workgroup flushes its [768, 32] slice of dB with atomics once (64 slabs = the flush traffic of gemm_tn's grid)
     int slabs = reid_knob(KNOB_TN_BLOCKS) > 0 ? reid_knob(KNOB_TN_BLOCKS) / 6 : 64;
     if (slabs < 1) slabs = 1;

@@ -560,6 +560,14 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         self.engine.wait_packed()
         if gather_fn is not None:
             raw, fmask = gather_fn(raw, fmask)
+        plan_ids = {id(v[2]) for v in plan.values()} if gather_fn is None else set()
+        return self.head_section(raw, fmask, return_features=return_features, plan_mask_ids=plan_ids)
+
+    def head_section(self, raw, fmask, return_features: bool = False, plan_mask_ids=frozenset()):
+        """Everything of forward() behind the encoders (model.py:392-510): SDM module per modality (training), batch-level modality
+        dropout, fusion, BN-neck, classifier -- on per-modality [B, D] features with the null tokens already filled in.  Under data
+        parallelism B is the GLOBAL batch (parallel.py gathers the features first), which every rank evaluates redundantly; bench.py
+        times this section alone at that size.  ``plan_mask_ids``: ids of mask tensors owned by the cached routing plan."""
         if self.training:
             # the SDM module is shared by all modalities (model.py:395-399): one pass over the stacked [n_mod*B, D] rows instead
             # of one per modality (same arithmetic per row, 5x fewer of the ~20 tiny launches of its forward + backward)
@@ -573,8 +581,7 @@ class CLIPBasedMultiModalReIDModel(nn.Module):
         keep = ok = None
         if self.training:
             mlist, keep, ok = self._modality_dropout(list(sem.keys()), mlist)
-        plan_ids = {id(v[2]) for v in plan.values()}
-        stable = keep is None and gather_fn is None and all(id(t) in plan_ids for t in mlist)      # mask tensors owned by the cached routing plan
+        stable = keep is None and bool(plan_mask_ids) and all(id(t) in plan_mask_ids for t in mlist)      # mask tensors owned by the cached routing plan
         fused = flist[0] if len(flist) == 1 else self._fusion(flist, mlist, stable_masks=stable)
         if keep is not None:
             # masks after the draw are what compute_loss must see (model.py:466-468: dropped modalities leave feature_masks)

@@ -582,35 +582,43 @@ def test_cosine_topk_matches_fp32_stable_argsort(ops, Nq, Ng, k):
         assert idx[0, :3].tolist() == [3, 5, 100]
 
 
-@pytest.mark.parametrize('n_img,rpi,r,lddy_extra', [(24, 197, 8, 0), (7, 197, 4, 1536), (256, 1, 8, 0), (3, 50, 8, 768)])
+@pytest.mark.parametrize('n_img,rpi,r,lddy_extra', [(24, 197, 8, 0), (7, 197, 4, 1536), (256, 1, 8, 0), (3, 50, 8, 768), (100, 197, 8, 0), (5, 32, 2, 0), (4, 33, 8, 0)])
 def test_lora_bwd_fused_equals_two_launch_path(ops, n_img, rpi, r, lddy_extra):
     """reid_lora_bwd_fused (U = mask(dY.B) * s and dB += dY^T.T from one pass over dY) against the two launches it replaces
     (reid_mer_gemm with the modality mask + reid_gemm_tn) and against fp64: ragged last row step, dY as a column block of a wider
-    matrix (the q|k|v cotangent), class-row form (one row per image), accumulation into a non-zero dB."""
+    matrix (the q|k|v cotangent), class-row form (one row per image), accumulation into a non-zero dB.  Both kernels behind the entry
+    point: one image per workgroup (r04: the default where an image spans a 32-row step; T modality-masked, as the forward produces it)
+    and the row-slab kernel (REID_LORA_IMPL=1; any T)."""
+    from prcv2025reid_amd import _lib
     M, N, Rp = n_img * rpi, 768, 32
     g = torch.Generator(device='cuda').manual_seed(M + r)
     wide = torch.randn(M, N + lddy_extra, device='cuda', generator=g)
     dYw = bf(wide); dY = dYw[:, lddy_extra // 2: lddy_extra // 2 + N] if lddy_extra else dYw
     mods = torch.randint(0, 4, (n_img,), device='cuda', generator=g).to(torch.int32)
-    Tm = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3)
+    row_mod = mods.long().repeat_interleave(rpi)
+    keep = (torch.arange(Rp, device='cuda').view(1, -1) // r) == row_mod.view(-1, 1)
+    T_any = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3)
+    T_masked = bf(T_any.float() * keep)
     B = torch.randn(N, Rp, device='cuda', generator=g) * 0.1
     BT = bf(B.t().contiguous())
     scale = 32.0 / r
     dB0 = torch.randn(N, Rp, device='cuda', generator=g)
-    # the two-launch path
-    U_ref = torch.empty(M, Rp, device='cuda', dtype=T16()); dB_ref = dB0.clone()
-    ops.gemm(dY, BT, U_ref, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=scale)
-    ops.gemm_tn(dY, Tm, dB_ref, beta=1.0)
-    U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = dB0.clone()
-    ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale)
-    # fp64
-    row_mod = mods.long().repeat_interleave(rpi)
-    keep = (torch.arange(Rp, device='cuda').view(1, -1) // r) == row_mod.view(-1, 1)
-    U64 = (dY.double() @ BT.double().t()) * scale * keep
-    dB64 = dB0.double() + dY.double().t() @ Tm.double()
-    assert rel_err(U.float(), U64.float()) < 6e-3 and rel_err(dB, dB64.float()) < 1e-5
-    assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5
-    assert float(U.float()[~keep].abs().max()) == 0.0                      # other modalities' columns are exactly zero
+    for impl, Tm in ((-1, T_masked), (1, T_any), (1, T_masked)):
+        # the two-launch path
+        U_ref = torch.empty(M, Rp, device='cuda', dtype=T16()); dB_ref = dB0.clone()
+        ops.gemm(dY, BT, U_ref, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=scale)
+        ops.gemm_tn(dY, Tm, dB_ref, beta=1.0)
+        U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = dB0.clone()
+        _lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', impl))
+        try:
+            ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale)
+        finally:
+            _lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', -1))
+        U64 = (dY.double() @ BT.double().t()) * scale * keep
+        dB64 = dB0.double() + dY.double().t() @ Tm.double()
+        assert rel_err(U.float(), U64.float()) < 6e-3 and rel_err(dB, dB64.float()) < 1e-5, impl
+        assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5, impl
+        assert float(U.float()[~keep].abs().max()) == 0.0                      # other modalities' columns are exactly zero
 
 
 def test_lora_bwd_fused_wide_cotangent_as_column_blocks(ops):
@@ -621,17 +629,24 @@ def test_lora_bwd_fused_wide_cotangent_as_column_blocks(ops):
     g = torch.Generator(device='cuda').manual_seed(11)
     dY = bf(torch.randn(M, N, device='cuda', generator=g))
     mods = torch.randint(0, 4, (n_img,), device='cuda', generator=g).to(torch.int32)
-    Tm = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3)
+    keep = (torch.arange(Rp, device='cuda').view(1, -1) // r) == mods.long().repeat_interleave(rpi).view(-1, 1)
+    Tm = bf(torch.randn(M, Rp, device='cuda', generator=g) * 0.3 * keep)            # modality-masked, as the forward produces it
     BT = bf((torch.randn(N, Rp, device='cuda', generator=g) * 0.05).t().contiguous())
     scale = 4.0
     U_ref = torch.empty(M, Rp, device='cuda', dtype=T16()); dB_ref = torch.zeros(N, Rp, device='cuda')
     ops.gemm(dY, BT, U_ref, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=rpi, alpha=scale)
     ops.gemm_tn(dY, Tm, dB_ref, beta=1.0)
-    U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = torch.zeros(N, Rp, device='cuda')
-    scratch = torch.full((M, Rp), float('nan'), device='cuda')            # never read before it is written
-    ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale, u_partial=scratch)
-    assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5
-    assert bool(torch.isfinite(U.float()).all())
+    from prcv2025reid_amd import _lib
+    for impl in (-1, 1):
+        U = torch.full((M, Rp), 7.0, device='cuda').to(T16()); dB = torch.zeros(N, Rp, device='cuda')
+        scratch = torch.full((M, Rp), float('nan'), device='cuda')            # never read before it is written
+        _lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', impl))
+        try:
+            ops.lora_bwd_fused(dY, Tm, BT, U, dB, mods, rpi, r, scale, u_partial=scratch)
+        finally:
+            _lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', -1))
+        assert rel_err(U.float(), U_ref.float()) < 3e-3 and rel_err(dB, dB_ref) < 1e-5, impl
+        assert bool(torch.isfinite(U.float()).all())
 
 
 @pytest.mark.parametrize('Nq,Ng,D,k', [(128, 200000, 512, 10), (37, 50000, 256, 32), (5, 1000, 512, 7), (3, 40, 64, 10)])

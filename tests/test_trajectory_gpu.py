@@ -36,22 +36,39 @@ def _delta_stats(keys, start, end_a, end_b):
     return (num / max(den, 1e-300)) ** 0.5, den ** 0.5
 
 
-# (gate on the adapter displacement, gate on the head displacement) by run: Adam's early steps are sign-like (step = lr * m / sqrt(v) ~ lr *
-# sign(g)), so a gradient entry whose sign the 16-bit operand noise flips contributes a full 2 lr of distance whatever its size; the
-# displacement distance therefore measures the FRACTION of near-zero gradient entries, not a parameter error, and is far above the
-# loss-level agreement.  Gates = what fp32 summation-order noise alone does to the oracle (measured below as `exact vs plain`) plus the
-# operand-noise share derived from the single-step gradient tolerance of tests/test_model_gpu.py (GRAD_TOL).
+# Gates.  The loss gates are DERIVED (oracle/bounds.py): the single-step bound at every one of the 30 steps.  The displacement gates are
+# 1.8x what the first run measured (profiles/r04_trajectory.log; MI355X): Adam's early steps are sign-like (step ~ lr * sign(g)), so a
+# gradient entry whose sign the 16-bit operand noise flips contributes a full 2 lr of distance whatever its size -- the displacement
+# distance measures the fraction of near-zero gradient entries, not a parameter error, and sits far above the loss-level agreement.
+#   measured, adapters: bf16 0.096-0.135 (of which the merged operand's rounding ALONE: 0.048-0.077), f16 0.029-0.042 (0.006-0.029)
+#   measured, head:     bf16 0.019-0.031, f16 0.004-0.006
+LORA_GATE = {'bf16': 0.25, 'f16': 0.08}
+HEAD_GATE = {'bf16': 0.06, 'f16': 0.015}
+_oracle_cache = {}
+
+
+def _oracle_run(key, state, arch, groups, scale, merged, kw, batch, tokens, labels):
+    """(losses, end state) of STEPS oracle steps; the plain run does not depend on the HIP flavor and is shared by both flavor cases."""
+    ck = key + (merged,)
+    if ck not in _oracle_cache:
+        t = so.TrajectoryOracle(state, arch, groups, lr_scale=scale, merged=merged, **kw)
+        ls = [t.step(batch['images'], tokens, batch['modality_mask'], labels)['total_loss'] for _ in range(STEPS)]
+        _oracle_cache[ck] = (ls, {k: t.state[k].detach() for k in t.keys})
+    return _oracle_cache[ck]
+
+
 @pytest.mark.parametrize('flavor', ['bf16', 'f16'])
 @pytest.mark.parametrize('init', ['reference', 'seeded'])
 @pytest.mark.parametrize('regime', ['reference_lr', 'adapters_x50'])
 def test_training_trajectory_vs_oracle(flavor, init, regime):
     from prcv2025reid_amd.trainer import FusedAdamW, StepDriver
     from test_model_gpu import build_model
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     z, meta = load_case('tiny_train_frozen')
     cfg, arch, state, batch, tokens = case_inputs(meta)
     if init == 'reference':                                   # mer_lora.py:37-38: lora_B = 0, the low-rank update starts at exactly 0
         state = {k: (torch.zeros_like(v) if k.endswith('lora_B.weight') else v) for k, v in state.items()}
-    groups = reference_trainable_groups('tiny_frozen')
+    groups = reference_trainable_groups('tiny_frozen')        # train.py:1418-1458: loras, bn_neck, null tokens
     scale = {'mer_loras': 50.0} if regime == 'adapters_x50' else 1.0
     kw = dict(contrastive_weight=meta['contrastive_weight'], tau=meta['tau'], ce_weight=meta['ce_weight'])
     labels = batch['person_id']
@@ -74,13 +91,12 @@ def test_training_trajectory_vs_oracle(flavor, init, regime):
         hip_losses.append(float(L['total_loss'].detach()))
     hip_end = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if torch.is_tensor(v)}
 
-    # ---- oracle: plain MERLinear, and the merged form with exact / flavor rounding of the merged operand
-    runs = {}
-    for name, merged in (('plain', None), ('exact', 'exact'), ('merged', flavor)):
-        t = so.TrajectoryOracle(state, arch, groups, lr_scale=scale, merged=merged, **kw)
-        ls = [t.step(batch['images'], tokens, batch['modality_mask'], labels)['total_loss'] for _ in range(STEPS)]
-        runs[name] = (ls, {k: t.state[k].detach() for k in t.keys})
-    keys = [k for k in runs['plain'][1] if k in hip_end]
+    # ---- oracle: plain MERLinear; and, in the regime the concern is about (updates far below one ulp of W: the reference's own learning
+    # rates), the merged form with this flavor's rounding of the merged operand -- everything else fp32
+    key = (init, regime)
+    plain = _oracle_run(key, state, arch, groups, scale, None, kw, batch, tokens, labels)
+    merged = _oracle_run(key, state, arch, groups, scale, flavor, kw, batch, tokens, labels) if regime == 'reference_lr' else None
+    keys = [k for k in plain[1] if k in hip_end]
     lora = [k for k in keys if '.loras.' in k]
     head = [k for k in keys if k.startswith('bn_neck.')]
     start = {k: state[k].float() for k in keys}
@@ -93,26 +109,23 @@ def test_training_trajectory_vs_oracle(flavor, init, regime):
                                            state, arch, True, labels=labels, loss_kw=kw)
     B, D = ref0['bn_features'].shape
     tol = bounds.loss_bound(flavor, B, D, kl['total_loss'])
-    gaps = [abs(a - b) for a, b in zip(hip_losses, runs['plain'][0])]
-    d_lora, n_lora = _delta_stats(lora, start, hip_end, runs['plain'][1])
-    d_head, n_head = _delta_stats(head, start, hip_end, runs['plain'][1])
-    m_lora, _ = _delta_stats(lora, start, runs['merged'][1], runs['plain'][1])
-    e_lora, _ = _delta_stats(lora, start, runs['exact'][1], runs['plain'][1])
-    m_gap = max(abs(a - b) for a, b in zip(runs['merged'][0], runs['plain'][0]))
-    print(f'\n  [{flavor} | init {init} | {regime}] loss {runs["plain"][0][0]:.4f} -> {runs["plain"][0][-1]:.4f} (oracle), '
+    gaps = [abs(a - b) for a, b in zip(hip_losses, plain[0])]
+    d_lora, n_lora = _delta_stats(lora, start, hip_end, plain[1])
+    d_head, n_head = _delta_stats(head, start, hip_end, plain[1])
+    print(f'\n  [{flavor} | init {init} | {regime}] loss {plain[0][0]:.4f} -> {plain[0][-1]:.4f} (oracle), '
           f'{hip_losses[0]:.4f} -> {hip_losses[-1]:.4f} (hip); max |loss gap| over {STEPS} steps = {max(gaps):.2e} (bound {tol:.2e}), '
           f'at the last step {gaps[-1]:.2e}')
-    print(f'    adapter displacement ||d|| = {n_lora:.3e}: hip vs oracle {d_lora:.3f} | oracle merged-{flavor} vs oracle {m_lora:.3f} '
-          f'(loss gap {m_gap:.2e}) | oracle merged-exact vs oracle {e_lora:.3f} (fp32 summation order alone)')
-    print(f'    head displacement ||d|| = {n_head:.3e}: hip vs oracle {d_head:.4f}')
+    msg = f'    adapter displacement ||d|| = {n_lora:.3e}: hip vs oracle {d_lora:.3f} (gate {LORA_GATE[flavor]})'
+    if merged is not None:
+        m_lora, _ = _delta_stats(lora, start, merged[1], plain[1])
+        m_gap = max(abs(a - b) for a, b in zip(merged[0], plain[0]))
+        msg += f' | the merged operand\'s {flavor} rounding alone (oracle, everything else fp32): {m_lora:.3f}, loss gap {m_gap:.2e}'
+        assert m_gap <= tol and m_lora <= LORA_GATE[flavor]
+    print(msg)
+    print(f'    head displacement ||d|| = {n_head:.3e}: hip vs oracle {d_head:.4f} (gate {HEAD_GATE[flavor]})')
     assert all(l == l for l in hip_losses)
     assert max(gaps) <= tol, (max(gaps), tol)
     assert hip_losses[-1] < 0.5 * hip_losses[0]              # it trains
-    assert d_head <= 0.05, d_head
-    assert d_lora <= LORA_GATE[(flavor, regime)], d_lora
+    assert d_head <= HEAD_GATE[flavor], d_head
+    assert d_lora <= LORA_GATE[flavor], d_lora
     assert n_lora > 0
-
-
-# relative distance of the adapter displacements after 30 steps (see the comment above the test).  Filled from the first measured run
-# (profiles/r04_trajectory.log) with 1.5x head-room; the loss-level gates above are derived, not measured.
-LORA_GATE = {('bf16', 'reference_lr'): 1.0, ('bf16', 'adapters_x50'): 1.0, ('f16', 'reference_lr'): 1.0, ('f16', 'adapters_x50'): 1.0}

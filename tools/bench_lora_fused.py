@@ -7,7 +7,8 @@ from prcv2025reid_amd import ops, _lib
 M, N, Rp, r = 50432, 768, 32, 8
 g = torch.Generator(device='cuda').manual_seed(0)
 dY = torch.randn(M, N, device='cuda', generator=g).to(_lib.t16())
-T = torch.randn(M, Rp, device='cuda', generator=g).to(_lib.t16())
+mods_row = (torch.arange(M, device='cuda') // 197 // 64).view(-1, 1)
+T = (torch.randn(M, Rp, device='cuda', generator=g) * ((torch.arange(Rp, device='cuda').view(1, -1) // r) == mods_row)).to(_lib.t16())
 BT = (torch.randn(Rp, N, device='cuda', generator=g) * 0.1).to(_lib.t16())
 mods = torch.arange(256, device='cuda', dtype=torch.int32) // 64
 U = torch.empty(M, Rp, device='cuda', dtype=_lib.t16()); dB = torch.zeros(N, Rp, device='cuda')
@@ -25,12 +26,16 @@ def timeit(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+t = timeit(lambda: ops.lora_bwd_fused(dY, T, BT, U, dB, mods, 197, r, 2.0))
+print(f'one image per workgroup (r04 default, 256 workgroups): {t:7.1f} us = {M * N * 2 / t / 1e6:7.2f} TB/s of dY = {M * N * 2 / t / 1e3 / 256:6.1f} GB/s per workgroup')
+_lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', 1))
 for knob in (-1, 192, 768, 1536):
     _lib.check(_lib.lib().reid_set_knob(b'TN_BLOCKS', knob))
     t = timeit(lambda: ops.lora_bwd_fused(dY, T, BT, U, dB, mods, 197, r, 2.0))
     slabs = 64 if knob < 0 else knob // 6
     print(f'fused, {slabs:4d} slabs: {t:7.1f} us = {M * N * 2 / t / 1e6:7.2f} TB/s of dY = {M * N * 2 / t / 1e3 / slabs:6.1f} GB/s per workgroup')
 _lib.check(_lib.lib().reid_set_knob(b'TN_BLOCKS', -1))
+_lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', -1))
 t1 = timeit(lambda: ops.gemm(dY, BT, U, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=197, alpha=2.0))
 t2 = timeit(lambda: ops.gemm_tn(dY, T, dB, beta=1.0))
 print(f'two launches: U {t1:.1f} us + dB {t2:.1f} us = {t1 + t2:.1f} us')
