@@ -204,6 +204,13 @@ int reid_pack_bf16_table(const float* src, void* dst_bf16, const int64_t* table,
 int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, int32_t ldt, const void* BT, int32_t ldbt, void* U, int32_t ldu,
                         float* dB, int32_t lddb, const int32_t* img_mod, int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t N,
                         int32_t Rp, float scale, float* u_partial, int32_t u_mode, void* stream);
+/* The other adapter gradient of a MERLinear, dA += U^T . X (autograd of lora_A, mer_lora.py:40-49), as one pass over the linear's INPUT
+ * X [M, K] (16-bit; K a multiple of 768): dA[g Rp + c, k] += sum_m U[m, g Rp + c] X[m, k] for the n_groups (1, or 3 for the fused q|k|v
+ * projection) adapter groups of Rp = 32 columns of U [M, n_groups Rp] (16-bit, modality-masked as reid_lora_bwd_fused writes it).
+ * dA: fp32 [n_groups Rp, K] (row stride ldda), accumulated with atomics.  One workgroup per (image, 768-column block): rows_per_img >= 32,
+ * mask_r a divisor of 16; other shapes: reid_gemm_tn(U, X). */
+int reid_lora_da_fused(const void* X, int32_t ldx, const void* U, int32_t ldu, float* dA, int32_t ldda, const int32_t* img_mod,
+                       int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t K, int32_t Rp, int32_t n_groups, void* stream);
 
 /* Merged MER-LoRA weights (mer_lora.py:80-99): for every table entry e and modality mu < nmod
  *     W_eff[e][mu] = W_e + scaling * Bcat_e[:, mu r : (mu+1) r] . Acat_e[g Rp + mu r : g Rp + (mu+1) r, :]      (16-bit, rounded once)

@@ -1004,8 +1004,11 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
     constexpr int LDS2 = 2 * NT * 32 * 128;
     REID_MAX_LDS((attn_bwd_dkv_kernel<NT>), LDS1);
     REID_MAX_LDS((attn_bwd_dq_kernel<NT>), LDS2);
-    // REID_ATTN_BWD: 1 = the two-kernel form, 2 = one pass, one item per workgroup, 3 = one pass, persistent; default: persistent when no
-    // query tile is pruned and there are at least two items per CU, else the one-item form.  Masked / causal attention: two kernels.
+    // REID_ATTN_BWD: 1 = the two-kernel form, 2 = one pass, one item per workgroup (default), 3 = one pass, persistent.  Masked / causal
+    // attention: two kernels.  Measured (r04, 256 images x 12 heads, profiles/r04_attn_bwd.log): 292 / 257 / 257 us alone; inside the training
+    // step 31.93 / 31.42 / 31.54 ms per step on one box -- the persistent form hides the image staging (top-of-item wait 1.0 us instead of
+    // 5.5 us) but pays it back in barriers and DMA issue (3.1 us between the phases), and like every persistent kernel it keeps its CUs
+    // from the side stream; the one-item form is the default.
     const int impl = reid_knob(KNOB_ATTN_BWD);
     if (!p.key_mask && !p.causal && impl != 1) {
         constexpr int LDSF = 4 * NT * 32 * 128 + 2 * NT * 32 * 4;
@@ -1013,7 +1016,7 @@ int launch_bwd(const AttnParams& p, hipStream_t s) {
         const int n_items = p.n_seq * p.heads;
         const int cus = reid_num_cus();
         const bool pers_ok = p.q_tiles <= 0 && (p.S + 31) / 32 == NT;
-        if (pers_ok && (impl == 3 || (impl <= 0 && n_items >= 2 * cus))) {
+        if (pers_ok && impl == 3) {
             REID_MAX_LDS((attn_bwd_pers_kernel<NT>), LDSP);
             hipLaunchKernelGGL(attn_bwd_pers_kernel<NT>, dim3(n_items < cus ? n_items : cus), dim3(NT * 64), LDSP, s, p, n_items);
             REID_CHECK_LAUNCH("reid_attn_bwd(persistent)");

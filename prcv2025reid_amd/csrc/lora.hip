@@ -288,10 +288,25 @@ constexpr int ROW_BYTES = N * 2;                           // 1536: 96 chunks of
 constexpr int IMG_BYTES = R * ROW_BYTES;                   // 48 KiB
 constexpr int T_BYTES = R * RP * 2;                        // 2 KiB
 constexpr int BUF_BYTES = IMG_BYTES + T_BYTES;
-constexpr int LDS_BYTES = 2 * BUF_BYTES;
+constexpr int NBUF = 3;                                      // ring of step buffers: two steps (96 KiB) in flight while one is read
+constexpr int USTAGE_BYTES = R * RP * 2;                    // U tile of a step, row-major, staged for whole-row stores
+constexpr int LDS_BYTES = NBUF * BUF_BYTES + USTAGE_BYTES;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 using fused::s4; using fused::lds_s4_ptr; using fused::Params;
+
+// One LDS-DMA wave-instruction (64 lanes x 16 bytes -> 1 KiB of LDS at `lds_base`, wave-uniform) issued from inline assembly: hipcc then
+// has no vector-memory operation of the ring in its scoreboard.  With the builtin it places `s_waitcnt vmcnt(0)` in front of every
+// ds_read_b64_tr_b16 while a DMA is outstanding -- the transposed reads of every step then wait for the WHOLE ring (first form of this
+// kernel: 10 GB/s per workgroup whatever the ring depth).  Consequently no other global access may sit inside the step loops below
+// (the compiler's own waits for it would drain the ring as well): outputs are kept in registers and written after the loop.
+// M0 = LDS base; nothing else in these kernels uses M0.
+typedef __attribute__((address_space(3))) char* lds_cptr;
+__device__ __forceinline__ uint32_t lds_addr(const char* ptr) { return (uint32_t)(uintptr_t)(lds_cptr)(char*)ptr; }
+__device__ __forceinline__ void dma16(const void* src, uint32_t lds_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+}
 
 // transposed operand from the swizzled image: 16 MFMA rows = image columns col0 .. col0 + 15, k = image rows 0 .. 31
 __device__ __forceinline__ bf16x8 tr_frag_swz(const char* img, int col0, int lane) {
@@ -306,6 +321,23 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const char* img, int col0, int lan
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// U = mask(Up) * scale in 16 bits once the last column block of a wide cotangent has added its partial sums (fp32 [M, 32]) to Up
+__global__ __launch_bounds__(256) void u_finish_kernel(const float* __restrict__ Up, bf16_t* __restrict__ U, int ldu, const int32_t* __restrict__ img_mod,
+                                                       int rows_per_img, int mask_r, float scale, int M) {
+    REID_T16_ENTER();
+    const int i = blockIdx.x * 256 + threadIdx.x;             // one thread per (row, pair of columns)
+    const int m = i >> 4, c = (i & 15) * 2;
+    if (m >= M) return;
+    const int mu = img_mod[m / rows_per_img];
+    const float a = Up[(size_t)m * RP + c], b = Up[(size_t)m * RP + c + 1];
+    *(uint32_t*)(U + (size_t)m * ldu + c) = pack_bf16x2(c / mask_r == mu ? a * scale : 0.f, (c + 1) / mask_r == mu ? b * scale : 0.f);
+}
+
+#ifdef REID_EXPERIMENTS
+#define LORA_ABL(bit) ((p.slab_rows >> (bit)) & 1)            // timing experiments (wrong results): REID_LORA_IMPL = 16 + bits, tools/exp_lora_ablate.py
+#else
+#define LORA_ABL(bit) 0
+#endif
 __global__ __launch_bounds__(512, 2) void lora_bwd_image_kernel(const Params p) {
     REID_T16_ENTER();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -322,8 +354,9 @@ __global__ __launch_bounds__(512, 2) void lora_bwd_image_kernel(const Params p) 
     const int steps = (rend - rbeg + R - 1) / R;
 
     // one step's operands -> LDS: 48 dY instructions (eight waves x six) + two T instructions (waves 0, 1)
+    const uint32_t smem_a = lds_addr(smem);
     auto issue = [&](int t, int buf) {
-        char* base = smem + buf * BUF_BYTES;
+        const uint32_t base = smem_a + buf * BUF_BYTES;
         const int r0 = rbeg + t * R;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -331,57 +364,116 @@ __global__ __launch_bounds__(512, 2) void lora_bwd_image_kernel(const Params p) 
             const int g = qd * 64 + lane;
             const int row = g / 96, c = g - row * 96;
             int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
-            const bf16_t* src = p.dY + (size_t)gr * p.lddy + ((c ^ (row & 15)) << 3);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + qd * 1024), 16, 0, 0);
+            dma16(p.dY + (size_t)gr * p.lddy + ((c ^ (row & 15)) << 3), base + qd * 1024);
         }
-        if (w < 2) {
+        if (w < 2 && !LORA_ABL(4)) {
             const int g = w * 64 + lane;                      // T tile: 32 rows x 4 chunks, lane-linear
             const int row = g >> 2, c = g & 3;
             int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.T + (size_t)gr * p.ldt + c * 8), (lptr_t)(base + IMG_BYTES + w * 1024), 16, 0, 0);
+            dma16(p.T + (size_t)gr * p.ldt + c * 8, base + IMG_BYTES + w * 1024);
         }
     };
     issue(0, 0);
+    if (steps > 1) issue(1, 1);
     // B^T fragments of the window (waves 0, 1: B operand of U = dY . B: n = adapter column w0 + l16, k = dY column)
     bf16x8 bfr[24];
-    if (w < 2) {
+    if (w < 2 && !LORA_ABL(5)) {
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks) bfr[ks] = *(const bf16x8*)(p.BT + (size_t)(w0 + l16) * p.ldbt + ks * 32 + 8 * fq);
+        // a use of every fragment HERE: the compiler tracks these loads and would otherwise wait for them with `vmcnt(0)` at their first use
+        // INSIDE the step loop -- on every step, draining the DMA ring the loop exists to keep full (first form: 10 GB/s per workgroup
+        // whatever the ring depth)
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) asm volatile("" ::"v"(bfr[ks]));
     }
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t pend_val = u32x4_t{0u, 0u, 0u, 0u};                // waves 0, 1: the previous step's output, not yet issued
+    void* pend_ptr = nullptr;
+    int pend_n = 0;                                            // rows (u_mode != 0) / "this lane has a row" (u_mode == 0) still to go out
+    auto flush_pending = [&]() {
+        if (LORA_ABL(1)) { pend_n = 0; return; }
+        if (p.u_mode == 0) {
+            if (pend_n) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(pend_ptr), "v"(pend_val) : "memory");
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= pend_n) continue;
+                float* pp = (float*)pend_ptr + (size_t)e * RP;
+                const unsigned vv = pend_val[e];
+                if (p.u_mode == 2) asm volatile("global_store_dword %0, %1, off" ::"v"(pp), "v"(vv) : "memory");
+                else asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(pp), "v"(vv) : "memory");
+            }
+        }
+        pend_n = 0;
+    };
+    int buf = 0;
     for (int t = 0; t < steps; ++t) {
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of step t has landed (and its U stores of step t - 1 are out)
-        __syncthreads();                                      // ... everybody's; and everybody is done reading the other buffer (step t - 1)
-        if (t + 1 < steps) issue(t + 1, buf ^ 1);
+        // this wave's share of step t has landed: everything but the DMA instructions of step t + 1 (the newest this wave has issued: six,
+        // seven in waves 0 and 1 which also fetch T) -- the two-byte U stores of the previous step are older than those and drain here too
+        if (t + 1 < steps) {
+            if (w < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... everybody's share; and everybody is done reading the buffer of step t - 1
+        __builtin_amdgcn_sched_barrier(0);
         const char* xs = smem + buf * BUF_BYTES;
         const char* ts = xs + IMG_BYTES;
         const int r0 = rbeg + t * R;
         if (w < 2) {
             // U[16 rows of this wave x 16 window columns]: the whole K = 768 contraction in this wave
-            f32x4 ua = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (four accumulators, fragment reads issued four at a time: one 24-long chain of read -> wait -> MFMA made this wave the slowest
+            //  of the workgroup -- ~1.7 us per step, the first form ran at 10 GB/s per workgroup whatever the depth of the DMA ring)
+            flush_pending();                                  // the PREVIOUS step's rows go out first: a whole step ahead of the next counted wait
+            f32x4 u4[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) u4[a] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int row = 16 * w + l16;
+            const char* xrow = xs + row * ROW_BYTES;
+            const int rsw = row & 15;
 #pragma unroll
-            for (int ks = 0; ks < 24; ++ks) {
-                const bf16x8 af = *(const bf16x8*)(xs + row * ROW_BYTES + (((4 * ks + fq) ^ (row & 15)) << 4));
-                ua = mfma16(af, bfr[ks], ua);
+            for (int k0 = 0; k0 < (LORA_ABL(0) ? 0 : 24); k0 += 4) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) af[a] = *(const bf16x8*)(xrow + (((4 * (k0 + a) + fq) ^ rsw) << 4));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) u4[a] = mfma16(af[a], bfr[k0 + a], u4[a]);
             }
-            // lane: column n = l16 of the window, rows 4 fq + e
+            const f32x4 ua = (u4[0] + u4[1]) + (u4[2] + u4[3]);
+            // Outputs: fire and forget from inline assembly (see dma16: no compiler-visible global access inside the loop), and issued ONE
+            // STEP LATE (`flush_pending` at the start of the next step's arithmetic, above): a store issued here would be the operation right
+            // in front of the next counted wait, which would then sit out its whole write acknowledgement (~1.7 us per step: every form of
+            // this kernel measured 29.5-29.9 us until the stores moved); issued a step ahead, the acknowledgement passes under the wait for
+            // the next step's DMA.
+            // lane: column n = l16 of the window, rows 4 fq + e.  u_mode: 0 = U (mask, scale, 16-bit); 2 = first column block of a wide
+            // cotangent: partial sum stored to Up; 3 / 1 = later blocks: added to Up (the host entry finishes U after the last block)
             const bool mine = l16 >= c_lo && l16 < c_hi;
+            if (p.u_mode == 0) {
+                // through LDS ([32 rows][32 adapter columns], 16-bit): the wave then writes its 16 rows as whole 64-byte rows (one 16-byte
+                // store per lane) -- two-byte stores straight from the accumulator layout were 112 wave-instructions of eight 32-byte pieces
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = r0 + 16 * w + 4 * fq + e;
-                if (m >= rend) continue;
-                float v = ua[e];
-                if (p.u_mode & 1) v += p.Up[(size_t)m * RP + w0 + l16];
-                if (p.u_mode & 2) {
-                    p.Up[(size_t)m * RP + w0 + l16] = v;
-                } else {
-                    p.U[(size_t)m * p.ldu + w0 + l16] = f32_to_bf16(mine ? v * p.scale : 0.f);
-                    p.U[(size_t)m * p.ldu + (w0 ^ 16) + l16] = f32_to_bf16(0.f);      // the other half of the 32 adapter columns: other modalities
+                for (int e = 0; e < 4; ++e) {
+                    bf16_t* ul = (bf16_t*)(smem + NBUF * BUF_BYTES) + (16 * w + 4 * fq + e) * RP;
+                    ul[w0 + l16] = f32_to_bf16(mine ? ua[e] * p.scale : 0.f);
+                    ul[(w0 ^ 16) + l16] = f32_to_bf16(0.f);                   // the other half of the 32 adapter columns: other modalities
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's 16 rows are in LDS (written and read by this wave only)
+                __builtin_amdgcn_wave_barrier();
+                const int row = 16 * w + (lane >> 2), ch = lane & 3;
+                pend_val = *(const u32x4_t*)(smem + NBUF * BUF_BYTES + row * (RP * 2) + ch * 16);
+                pend_ptr = (void*)(p.U + (size_t)(r0 + row) * p.ldu + ch * 8);
+                pend_n = (r0 + row) < rend ? 1 : 0;
+            } else {
+                pend_val = u32x4_t{__float_as_uint(ua[0]), __float_as_uint(ua[1]), __float_as_uint(ua[2]), __float_as_uint(ua[3])};
+                pend_ptr = (void*)(p.Up + (size_t)(r0 + 16 * w + 4 * fq) * RP + w0 + l16);
+                const int left = rend - (r0 + 16 * w + 4 * fq);            // rows e = 0 .. left - 1 of this lane exist
+                pend_n = left < 0 ? 0 : (left > 4 ? 4 : left);
             }
         } else {
             // dB[128 columns of this wave, window] += dY^T . T over the rows of this step (rows beyond the image: T fragment zeroed)
@@ -395,18 +487,136 @@ __global__ __launch_bounds__(512, 2) void lora_bwd_image_kernel(const Params p) 
             }
             const int cbase = (w - 2) * 128;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = mfma16(tr_frag_swz(xs, cbase + i * 16, lane), tf, acc[i]);
+            for (int i = 0; i < (LORA_ABL(2) ? 0 : 8); ++i) acc[i] = mfma16(tr_frag_swz(xs, cbase + i * 16, lane), tf, acc[i]);
+        }
+        // step t + 2 into the buffer step t - 1 was read from (every wave is past this step's barrier, hence done with it); issued AFTER
+        // this step's U stores so that the counted wait above has exactly one step's DMA instructions behind everything it waits for
+        const int nb = buf == 0 ? NBUF - 1 : buf - 1;        // (t + 2) % NBUF == (t - 1) % NBUF
+        if (t + 2 < steps) issue(t + 2, nb);
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+    if (w < 2) flush_pending();                               // the last step's U rows
+    // dB of this image: through LDS (the ring is idle now) so that every atomic wave-instruction has 64 active lanes = eight dY columns x the
+    // modality's r adapter columns -- straight from the accumulator layout half of the lanes of each of 192 instructions were masked out
+    __syncthreads();
+    float* fl = (float*)smem;                                 // [768 dY columns][16 window columns]
+    if (w >= 2) {
+        const int cbase = (w - 2) * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fl[(cbase + i * 16 + 4 * fq + e) * 16 + l16] = acc[i][e];
+    }
+    __syncthreads();
+    {
+        const int rr = p.mask_r, total = N * rr;
+        for (int idx = tid; idx < (LORA_ABL(3) ? 0 : total); idx += 512) {
+            const int col = idx / rr, j = idx - col * rr;
+            atomicAdd(p.dB + (size_t)col * p.lddb + mu * rr + j, fl[col * 16 + c_lo + j]);
         }
     }
-    if (w >= 2) {
-        // acc[i]: rows = dY columns cbase + 16 i + 4 fq + e, column = window column l16; only this modality's columns carry anything
-        if (l16 >= c_lo && l16 < c_hi) {
-            const int cbase = (w - 2) * 128;
+}
+
+// dA of one MERLinear in the same form: dA[g Rp + c, k] += sum_m U[m, g Rp + c] . X[m, k] -- one image (one modality) per workgroup and
+// 768-column block of X, the X tile of a 32-row step by LDS-DMA into the same swizzled image, the U windows (G groups x 16 columns) beside it,
+// all eight waves accumulate [96 columns x 16] per group from transposed reads; 768 x r fp32 atomics per group at the end.  Replaces
+// reid_gemm_tn(U, X) for the adapter gradients (r03: 48 launches x 70-75 us inside the step).  U must be modality-masked (it is: reid_lora_bwd_fused
+// and the mask epilogue of reid_mer_gemm write zeros elsewhere).
+struct DaParams {
+    const bf16_t* X; const bf16_t* U; float* dA;
+    const int32_t* img_mod;
+    int ldx, ldu, ldda, rows_per_img, mask_r, M, Rp;
+};
+template <int G>
+__global__ __launch_bounds__(512, 2) void lora_da_image_kernel(const DaParams p) {
+    REID_T16_ENTER();
+    constexpr int UB = 4096;                                  // U windows of a step: G x [32 rows][16 columns] 16-bit (<= 3 KiB), padded
+    constexpr int BUF = IMG_BYTES + UB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, fq = lane >> 4;
+    const int img = blockIdx.x, cblk = blockIdx.y;
+    const int rbeg = img * p.rows_per_img;
+    const int rend = min(p.M, rbeg + p.rows_per_img);
+    if (rbeg >= rend) return;
+    const int mu = p.img_mod[img];
+    const int w0 = (mu * p.mask_r) & ~15;
+    const int c_lo = mu * p.mask_r - w0, c_hi = c_lo + p.mask_r;
+    const int steps = (rend - rbeg + R - 1) / R;
+    const bf16_t* Xb = p.X + (size_t)cblk * N;
+    const uint32_t smem_a = lds_addr(smem);
+    auto issue = [&](int t, int buf) {
+        const uint32_t base = smem_a + buf * BUF;
+        const int r0 = rbeg + t * R;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(p.dB + (size_t)(cbase + i * 16 + 4 * fq + e) * p.lddb + w0 + l16, acc[i][e]);
+        for (int j = 0; j < 6; ++j) {
+            const int qd = w * 6 + j;
+            const int g = qd * 64 + lane;
+            const int row = g / 96, c = g - row * 96;
+            int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
+            dma16(Xb + (size_t)gr * p.ldx + ((c ^ (row & 15)) << 3), base + qd * 1024);
         }
+        if (w < G) {                                          // group w's window: 32 rows x 2 chunks, lane-linear (row pitch 32 bytes)
+            const int row = lane >> 1, c = lane & 1;
+            int gr = r0 + row; gr = gr < rend ? gr : rend - 1;
+            dma16(p.U + (size_t)gr * p.ldu + w * p.Rp + w0 + c * 8, base + IMG_BYTES + w * 1024);
+        }
+    };
+    issue(0, 0);
+    if (steps > 1) issue(1, 1);
+    f32x4 acc[G][6];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int t = 0; t < steps; ++t) {
+        if (t + 1 < steps) {                                  // all but the newest step's DMA instructions (six, seven in the waves that fetch U)
+            if (w < G) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* xs = smem + buf * BUF;
+        const char* us = xs + IMG_BYTES;
+        const int nvalid = rend - (rbeg + t * R);
+        bf16x8 uf[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uf[g] = fused::tr_frag(us + g * 1024, 32, 0, 0, lane);
+            if (nvalid < R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (16 * (j >> 2) + 4 * fq + (j & 3) >= nvalid) uf[g][j] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bf16x8 xf = tr_frag_swz(xs, w * 96 + i * 16, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][i] = mfma16(uf[g], xf, acc[g][i]);      // (U first: a lane then owns ONE X column, l16 = 16 consecutive k of dA)
+        }
+        const int nb = buf == 0 ? NBUF - 1 : buf - 1;
+        if (t + 2 < steps) issue(t + 2, nb);
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+    // acc[g][i]: row = window column 4 fq + e of group g (an adapter row of dA), column = X column w 96 + 16 i + l16: an atomic wave-instruction
+    // covers 16 consecutive k of up to four adapter rows (64-byte runs).  The first form had the operands the other way round -- every lane a
+    // different ROW of dA, 3 KiB apart: the 17x-slower atomic shape of MI355X_MICROARCH.md, and the step 0.85 ms slower than with reid_gemm_tn.
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * fq + e;
+        if (c < c_lo || c >= c_hi) continue;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                atomicAdd(p.dA + (size_t)(g * p.Rp + w0 + c) * p.ldda + (size_t)cblk * N + w * 96 + i * 16 + l16, acc[g][i][e]);
     }
 }
 }  // namespace image
@@ -429,8 +639,16 @@ extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, 
     if (reid_knob(KNOB_LORA_IMPL) != 1 && rows_per_img >= image::R && mask_r <= 16 && 16 % mask_r == 0) {
         REID_MAX_LDS((image::lora_bwd_image_kernel), image::LDS_BYTES);
         const int n_img = (M + rows_per_img - 1) / rows_per_img;
+#ifdef REID_EXPERIMENTS
+        p.slab_rows = reid_knob(KNOB_LORA_IMPL) >= 16 ? reid_knob(KNOB_LORA_IMPL) - 16 : 0;
+#endif
         hipLaunchKernelGGL(image::lora_bwd_image_kernel, dim3(n_img), dim3(512), image::LDS_BYTES, (hipStream_t)stream, p);
         REID_CHECK_LAUNCH("reid_lora_bwd_fused(image)");
+        if (u_mode == 1) {                                    // last column block of a wide cotangent: every partial sum is in Up now
+            hipLaunchKernelGGL(image::u_finish_kernel, dim3((M * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)u_partial, (bf16_t*)U,
+                               ldu, img_mod, rows_per_img, mask_r, scale, M);
+            REID_CHECK_LAUNCH("reid_lora_bwd_fused(finish)");
+        }
         return REID_OK;
     }
     // few, long slabs: each workgroup flushes its [768, 32] slice of dB with atomics once (64 slabs = the flush traffic of gemm_tn's grid)
@@ -441,6 +659,27 @@ extern "C" int reid_lora_bwd_fused(const void* dY, int32_t lddy, const void* T, 
     REID_MAX_LDS((fused::lora_bwd_fused_kernel<8>), fused::Geo<8>::LDS_BYTES);
     hipLaunchKernelGGL(fused::lora_bwd_fused_kernel<8>, dim3(slabs), dim3(512), fused::Geo<8>::LDS_BYTES, (hipStream_t)stream, p);
     REID_CHECK_LAUNCH("reid_lora_bwd_fused");
+    return REID_OK;
+}
+
+extern "C" int reid_lora_da_fused(const void* X, int32_t ldx, const void* U, int32_t ldu, float* dA, int32_t ldda, const int32_t* img_mod,
+                                  int32_t rows_per_img, int32_t mask_r, int32_t M, int32_t K, int32_t Rp, int32_t n_groups, void* stream) {
+    REID_CHECK_ARG(X && U && dA && img_mod, "reid_lora_da_fused: null pointer");
+    REID_CHECK_ARG(M > 0 && K > 0 && K % 768 == 0 && Rp == 32 && (n_groups == 1 || n_groups == 3), "reid_lora_da_fused: M=%d K=%d Rp=%d groups=%d (K a multiple of 768, Rp = 32, 1 or 3 groups)", M, K, Rp, n_groups);
+    REID_CHECK_ARG(rows_per_img >= image::R && mask_r > 0 && mask_r <= 16 && 16 % mask_r == 0, "reid_lora_da_fused: rows_per_img=%d (>= 32) mask_r=%d (a divisor of 16)", rows_per_img, mask_r);
+    REID_CHECK_ARG(ldx % 8 == 0 && ldu % 8 == 0 && ldx >= K && ldu >= n_groups * Rp && ldda >= K, "reid_lora_da_fused: leading dimensions");
+    REID_CHECK_ARG(((uintptr_t)X | (uintptr_t)U) % 16 == 0, "reid_lora_da_fused: operand alignment");
+    image::DaParams p{(const bf16_t*)X, (const bf16_t*)U, dA, img_mod, ldx, ldu, ldda, rows_per_img, mask_r, M, Rp};
+    const int n_img = (M + rows_per_img - 1) / rows_per_img;
+    constexpr int LDS = image::NBUF * (image::IMG_BYTES + 4096);
+    if (n_groups == 1) {
+        REID_MAX_LDS((image::lora_da_image_kernel<1>), LDS);
+        hipLaunchKernelGGL(image::lora_da_image_kernel<1>, dim3(n_img, K / 768), dim3(512), LDS, (hipStream_t)stream, p);
+    } else {
+        REID_MAX_LDS((image::lora_da_image_kernel<3>), LDS);
+        hipLaunchKernelGGL(image::lora_da_image_kernel<3>, dim3(n_img, K / 768), dim3(512), LDS, (hipStream_t)stream, p);
+    }
+    REID_CHECK_LAUNCH("reid_lora_da_fused");
     return REID_OK;
 }
 

@@ -157,6 +157,7 @@ class Engine:
         self.add_ln = os.environ.get('REID_ADD_LN', '1') != '0'
         self.lora_down_defer = os.environ.get('REID_LORA_DOWN_DEFER', '1') != '0'
         self.lora_fused = os.environ.get('REID_LORA_FUSED', '1') != '0'
+        self.lora_da_fused = os.environ.get('REID_LORA_DA_FUSED', '1') != '0'
         self.lora_fused_max_n = 768 if os.environ.get('REID_LORA_FUSED') == '768' else 1 << 30      # (A/B: only the 768-column linears)
         self.W = {}
         self.W32 = {}
@@ -587,7 +588,14 @@ class Engine:
                             ops.gemm(dY, BT, U, **kw)
                         rest = tns
                     for xx, yy, out in rest:
-                        if not _EXP_SKIP_DA:                 # (timing experiment only: REID_EXP_SKIP_DA=1 leaves dA unwritten)
+                        if _EXP_SKIP_DA:                     # (timing experiment only: REID_EXP_SKIP_DA=1 leaves dA unwritten)
+                            continue
+                        # (xx, yy, out) = (U [M, G Rp], the linear's input X [M, K], dA [G Rp, K]): one pass over X, one image per workgroup
+                        ng = xx.shape[1] // Rp
+                        if self.lora_da_fused and xx.shape[1] == ng * Rp and out.shape[0] == ng * Rp and \
+                                ops.lora_da_fused_ok(yy.shape[1], Rp, kw['rows_per_img'], kw['mask_r'], ng):
+                            ops.lora_da_fused(yy, xx, out, kw['img_mod'], kw['rows_per_img'], kw['mask_r'], n_groups=ng)
+                        else:
                             ops.gemm_tn(xx, yy, out, beta=1.0)
             if side is None:
                 run()

@@ -194,6 +194,16 @@ def lora_bwd_fused(dY, T, BT, U, dB, img_mod, rows_per_img, mask_r, scale, u_par
                                         C.c_float(scale), ptr(u_partial), mode, stream_ptr()))
 
 
+def lora_da_fused(X, U, dA, img_mod, rows_per_img, mask_r, n_groups=1):
+    """dA += U^T . X for the adapter groups of one MERLinear, one pass over X (one image per workgroup); see reid_lora_da_fused."""
+    check(lib().reid_lora_da_fused(ptr(X), X.stride(0), ptr(U), U.stride(0), ptr(dA), dA.stride(0), ptr(img_mod), rows_per_img, mask_r,
+                                   X.shape[0], X.shape[1], U.shape[1] // n_groups, n_groups, stream_ptr()))
+
+
+def lora_da_fused_ok(K, Rp, rows_per_img, mask_r, n_groups):
+    return K % 768 == 0 and Rp == 32 and rows_per_img >= 32 and mask_r <= 16 and 16 % mask_r == 0 and n_groups in (1, 3)
+
+
 def lora_bwd_fused_ok(N, Rp):
     return N % 768 == 0 and N // 768 in (1, 2, 3, 4) and Rp == 32
 

@@ -621,6 +621,28 @@ def test_lora_bwd_fused_equals_two_launch_path(ops, n_img, rpi, r, lddy_extra):
         assert float(U.float()[~keep].abs().max()) == 0.0                      # other modalities' columns are exactly zero
 
 
+@pytest.mark.parametrize('n_img,rpi,r,K,G', [(24, 197, 8, 768, 1), (9, 197, 8, 3072, 1), (11, 197, 8, 768, 3), (3, 50, 4, 768, 3), (100, 197, 8, 768, 1), (5, 33, 2, 1536, 1)])
+def test_lora_da_fused_equals_gemm_tn(ops, n_img, rpi, r, K, G):
+    """reid_lora_da_fused (dA += U^T . X, one image per workgroup, the U windows of the image's modality only) against reid_gemm_tn(U, X)
+    and fp64: one and three adapter groups (q|k|v), column blocks of a wide input (fc2's 3072), ragged last step, accumulation into a
+    non-zero dA; rows of other modalities' adapters stay untouched."""
+    M, Rp = n_img * rpi, 32
+    g = torch.Generator(device='cuda').manual_seed(M + K + G)
+    X = bf(torch.randn(M, K, device='cuda', generator=g))
+    mods = torch.randint(0, 4, (n_img,), device='cuda', generator=g).to(torch.int32)
+    row_mod = mods.long().repeat_interleave(rpi)
+    keep = ((torch.arange(G * Rp, device='cuda').view(1, -1) % Rp) // r) == row_mod.view(-1, 1)
+    U = bf(torch.randn(M, G * Rp, device='cuda', generator=g) * 0.2 * keep)
+    dA0 = torch.randn(G * Rp, K, device='cuda', generator=g)
+    ref = dA0.clone()
+    ops.gemm_tn(U, X, ref, beta=1.0)
+    dA = dA0.clone()
+    assert ops.lora_da_fused_ok(K, Rp, rpi, r, G)
+    ops.lora_da_fused(X, U, dA, mods, rpi, r, n_groups=G)
+    want = dA0.double() + U.double().t() @ X.double()
+    assert rel_err(dA, want.float()) < 1e-5 and rel_err(dA, ref) < 1e-5
+
+
 def test_lora_bwd_fused_wide_cotangent_as_column_blocks(ops):
     """fc1's cotangent has 3072 columns: four launches over 768-column blocks, U summed through the fp32 scratch, equal the two-launch
     path on the whole matrix."""

@@ -39,3 +39,13 @@ _lib.check(_lib.lib().reid_set_knob(b'LORA_IMPL', -1))
 t1 = timeit(lambda: ops.gemm(dY, BT, U, img_mod=mods, mask_r=r, mask_period=Rp, rows_per_img=197, alpha=2.0))
 t2 = timeit(lambda: ops.gemm_tn(dY, T, dB, beta=1.0))
 print(f'two launches: U {t1:.1f} us + dB {t2:.1f} us = {t1 + t2:.1f} us')
+
+# ---- dA = U^T X: one image per workgroup (r04) against reid_gemm_tn
+for K, G in ((768, 1), (3072, 1), (768, 3)):
+    X = torch.randn(M, K, device='cuda', generator=g).to(_lib.t16())
+    keepG = ((torch.arange(G * Rp, device='cuda').view(1, -1) % Rp) // r) == mods_row
+    UU = (torch.randn(M, G * Rp, device='cuda', generator=g) * keepG).to(_lib.t16())
+    dA = torch.zeros(G * Rp, K, device='cuda')
+    t1 = timeit(lambda: ops.lora_da_fused(X, UU, dA, mods, 197, r, n_groups=G))
+    t2 = timeit(lambda: ops.gemm_tn(UU, X, dA, beta=1.0))
+    print(f'dA K={K} groups={G}: image kernel {t1:6.1f} us = {M * K * 2 / t1 / 1e6:5.2f} TB/s of X | gemm_tn {t2:6.1f} us = {M * K * 2 / t2 / 1e6:5.2f} TB/s')
