@@ -998,8 +998,11 @@ extern "C" int reid_cosine_topk_stream(const float* Qf, const float* Gf, int32_t
         const int rows_env = reid_knob(KNOB_STREAM_ROWS);
         const int n_ent = groups * k;
         const size_t lds_fast = (size_t)((n_ent + 3) & ~3) * 8 + (size_t)merge_survivor_cap(n_ent, k) * 8;
-        // one query and lists that fit the LDS next to a second resident workgroup: the last-arriving workgroup merges (no second launch)
-        const bool fuse = nq == 1 && lds_fast <= 72 * 1024 && reid_knob(KNOB_STREAM_GROUPS) != 0;
+        // REID_STREAM_FUSE=1 (one query, lists that fit the LDS next to a second resident workgroup): the last-arriving workgroup merges inside
+        // the scan launch.  Built for the r03 verdict's ">= 70 % of HBM end to end"; measured (r04, profiles/r04_stream_fused_merge.log):
+        // 78.1-78.5 us per call against 77.0-78 us with the separate merge launch -- the launch boundary it removes (~1.5 us) is what the
+        // hand-off costs (drain + barrier + ticket + 40 KiB of sc1 loads behind the slowest scan workgroup), so it is OFF by default.
+        const bool fuse = nq == 1 && lds_fast <= 72 * 1024 && reid_knob(KNOB_STREAM_FUSE) == 1;
         int32_t* counter = (int32_t*)((char*)ws + (size_t)SQ * stream_groups(k) * k * 8);
 #define REID_STREAM_LAUNCH1(DJ, R, P) hipLaunchKernelGGL((stream_topk_kernel<DJ, R, P>), dim3(groups), dim3(256), 0, s, Q, Gf, Ng, eq, exclude_g, nq, k, ps, pi)
 #define REID_STREAM_LAUNCHF(DJ, R) do { REID_MAX_LDS((stream_topk_kernel<DJ, R, 1, true>), 72 * 1024); \

@@ -744,8 +744,17 @@ def test_cosine_topk_one_query_fused_merge_repeated_calls(ops):
     G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
     Q = torch.nn.functional.normalize(torch.randn(40, D, device='cuda', generator=g), dim=1)
     G[77] = G[12345]; Q[3] = G[12345]
+    from prcv2025reid_amd import _lib
     index = GalleryIndex(G, normalized=True)
     want_i, want_s = index.topk(Q, k=10, normalized=True, stream=False)
+    _lib.check(_lib.lib().reid_set_knob(b'STREAM_FUSE', 1))                         # (off by default: no faster than the merge launch)
+    try:
+        _fused_merge_checks(index, Q, want_i, want_s)
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'STREAM_FUSE', -1))
+
+
+def _fused_merge_checks(index, Q, want_i, want_s):
     got = [index.topk(Q[i:i + 1], k=10, normalized=True) for i in range(40)]          # no synchronisation in between
     torch.cuda.synchronize()
     for i, (gi, gs) in enumerate(got):

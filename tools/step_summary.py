@@ -3,7 +3,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
 fam = [('gemm_pp', r'mer_gemm_pps?_kernel'), ('gemm128', r'mer_gemm_kernel<128, 128'), ('gemm_skinny', r'mer_gemm_kernel<(64|256|128), (32|64)'),
-       ('gemm_tn', r'gemm_tn_kernel'), ('lora_fused(64 CUs)', r'lora_bwd_fused'), ('attn', r'attn_'), ('ln', r'(add_)?ln_(fwd|bwd)'), ('merge/pack', r'merge_lora|pack_table'), ('sdm', r'sdm_'),
+       ('gemm_tn', r'gemm_tn_kernel'), ('lora image (r04)', r'lora_bwd_image|lora_da_image|u_finish'), ('lora_fused(64 CUs)', r'lora_bwd_fused'), ('attn', r'attn_'), ('ln', r'(add_)?ln_(fwd|bwd)'), ('merge/pack', r'merge_lora|pack_table'), ('sdm', r'sdm_'),
        ('opt', r'opt_'), ('head', r'sgemm|small_attn|bnneck|ce_|masked_mean|eltwise|l2norm'), ('aten/other', r'.')]
 tot = {f: [0.0, 0] for f, _ in fam}
 for r in rows:
