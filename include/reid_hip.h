@@ -132,6 +132,8 @@ int reid_gemm_tn(const void* X, const void* Y, float* C, int32_t M, int32_t P, i
  *        accumulated) only when non-NULL.  row_index != NULL scatters into rows of dx.
  *        bf16_row_scale != NULL: the 16-bit copy is dx * bf16_row_scale[row / rows_per_img] (the gradient entering a
  *        DropPath-scaled residual branch); the f32 dx is unscaled.
+ *        dx_dtype: REID_F32, or REID_F16 = the residual-stream gradient (dres read AND dx written) in IEEE half, saturating:
+ *        12 instead of 16 bytes per element; the caller keeps the stream inside half's range by scaling the loss.
  * ------------------------------------------------------------------------------------------ */
 int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma,
                        const float* beta, void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd,
@@ -146,7 +148,7 @@ int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y_bf16, int3
                            float* mean, float* rstd, int32_t rows, int32_t cols, float eps, void* stream);
 int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
                        const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
-                       const float* dres, float* dx, void* dx_bf16, int32_t lddx,
+                       const void* dres, void* dx, int32_t dx_dtype, void* dx_bf16, int32_t lddx,
                        float* dgamma, float* dbeta, int32_t rows, int32_t cols,
                        const float* bf16_row_scale, int32_t rows_per_img, void* stream);
 

@@ -205,15 +205,18 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // partial sums in registers over all its rows and adds them to memory ONCE (one atomic per column per wave instead of one per
 // element: 50k rows x 768 columns would otherwise serialise on 768 addresses).  Without dgamma/dbeta the launch has one
 // wave per row and the loop body runs once.
-template <bool DY_BF16, bool AFFINE>
+// DX_HALF: the residual-stream gradient (dres read, dx written) in IEEE half instead of fp32: 12 instead of 16 bytes per element of
+// this HBM-bound kernel.  The caller scales the loss so that the stream sits in half's range (engine.py: loss_scaling).
+template <bool DY_BF16, bool AFFINE, bool DX_HALF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                      const int32_t* __restrict__ row_index, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     const void* __restrict__ dres_, void* __restrict__ dx_,
                                                      bf16_t* __restrict__ dxb, int lddx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows, int cols,
                                                      const float* __restrict__ bscale, int rows_per_img) {
     REID_T16_ENTER();
+    if (DX_HALF) REID_F16_SATURATE();
     const int lane = threadIdx.x & 63;
     const int nv = cols >> 2;
     constexpr bool affine = AFFINE;                       // (a separate instantiation: the accumulators cost the default path 5 % of its bandwidth)
@@ -260,11 +263,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - m1 - xh[i][e] * m2);
-                if (dres) {
-                    const f32x4 r = *(const f32x4*)(dres + xrow * lddx + c * 4);
-                    o += r;
+                if (DX_HALF) {
+                    if (dres_) {
+                        const uint2 r = *(const uint2*)((const unsigned short*)dres_ + xrow * lddx + c * 4);
+                        o[0] += f16_to_f32((unsigned short)(r.x & 0xffffu)); o[1] += f16_to_f32((unsigned short)(r.x >> 16));
+                        o[2] += f16_to_f32((unsigned short)(r.y & 0xffffu)); o[3] += f16_to_f32((unsigned short)(r.y >> 16));
+                    }
+                    *(uint2*)((unsigned short*)dx_ + xrow * lddx + c * 4) = uint2{pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3])};
+                } else {
+                    if (dres_) {
+                        const f32x4 r = *(const f32x4*)((const float*)dres_ + xrow * lddx + c * 4);
+                        o += r;
+                    }
+                    *(f32x4*)((float*)dx_ + xrow * lddx + c * 4) = o;
                 }
-                *(f32x4*)(dx + xrow * lddx + c * 4) = o;
                 if (dxb) *(uint2*)(dxb + xrow * lddx + c * 4) = uint2{pack_bf16x2(o[0] * bs, o[1] * bs), pack_bf16x2(o[2] * bs, o[3] * bs)};
             }
         }
@@ -422,9 +434,10 @@ extern "C" int reid_add_layernorm_fwd(const float* x, int32_t ldx, const void* y
 
 extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy, const float* x, int32_t ldx,
                                   const int32_t* row_index, const float* gamma, const float* mean, const float* rstd,
-                                  const float* dres, float* dx, void* dx_bf16, int32_t lddx, float* dgamma, float* dbeta,
+                                  const void* dres, void* dx, int32_t dx_dtype, void* dx_bf16, int32_t lddx, float* dgamma, float* dbeta,
                                   int32_t rows, int32_t cols, const float* bf16_row_scale, int32_t rows_per_img, void* stream) {
     REID_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "reid_layernorm_bwd: null pointer");
+    REID_CHECK_ARG(dx_dtype == REID_F32 || dx_dtype == REID_F16, "reid_layernorm_bwd: dx_dtype must be REID_F32 or REID_F16");
     REID_CHECK_ARG(!bf16_row_scale || rows_per_img > 0, "reid_layernorm_bwd: bf16_row_scale needs rows_per_img");
     REID_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * MAXV, "reid_layernorm_bwd: cols=%d unsupported", cols);
     REID_CHECK_ARG(lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "reid_layernorm_bwd: ld");
@@ -433,9 +446,12 @@ extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy
     dim3 g(blocks), b(256);
     hipStream_t s = (hipStream_t)stream;
     const bool aff = dgamma || dbeta;
+    const bool hx = dx_dtype == REID_F16;
 #define REID_LN_BWD(B16, AFF)                                                                                                  \
-    hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
-                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img)
+    do { if (hx) hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, true>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
+                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img);                       \
+         else hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, false>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
+                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img); } while (0)
     if (dy_dtype == REID_BF16) { if (aff) REID_LN_BWD(true, true); else REID_LN_BWD(true, false); }
     else { if (aff) REID_LN_BWD(false, true); else REID_LN_BWD(false, false); }
 #undef REID_LN_BWD

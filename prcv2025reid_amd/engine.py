@@ -137,6 +137,9 @@ class Engine:
         # bf16 has fp32's exponent range and needs none of this.
         self.flavor = _lib.flavor()
         self.loss_scaling = self.flavor == 'f16'
+        # The residual-stream gradient of the vision tower (dx between the LayerNorm backward kernels) in IEEE half: those kernels
+        # are HBM-bound and move 12 instead of 16 bytes per element.  Needs the same scaling in either flavor.
+        self.dx_half = os.environ.get('REID_DX_HALF', '1') != '0'
         self._dense_ver = None
         self._lora_ver = None
         self._lora_pack = None
@@ -492,20 +495,21 @@ class Engine:
         gA = lambda l, nm: lay.view_A(grad, l, nm)
         gB = lambda l, nm: lay.view_B(grad, l, nm)
         scale_t = None
-        if self.loss_scaling:
+        if self.loss_scaling or self.dx_half:
             amax = dfeat.abs().amax().clamp_min(1e-30)
             scale_t = torch.exp2(torch.floor(torch.log2(512.0 / amax))).clamp(2.0 ** -20, 2.0 ** 40)
             dfeat = dfeat * scale_t
         dfb = ops.to_bf16(dfeat)
+        gx = dict(dtype=torch.float16 if self.dx_half else torch.float32, device=dev)      # the residual-stream gradient
         dcls = torch.empty(n_img, d, **b16)
         ops.gemm(dfb, W['vprojT'], dcls)
         prune = bool(st.get('cls_prune'))
         idxl = st['idxl']
         if prune:                                           # class rows only until the last block's attention (see vision_forward)
-            dx = torch.empty(M, d, **f32); dxb = torch.empty(M, d, **b16)       # first written (all rows) by the last block's LN1 backward
-            dx_c = torch.empty(n_img, d, **f32); dxb_c = torch.empty(n_img, d, **b16)
+            dx = torch.empty(M, d, **gx); dxb = torch.empty(M, d, **b16)        # first written (all rows) by the last block's LN1 backward
+            dx_c = torch.empty(n_img, d, **gx); dxb_c = torch.empty(n_img, d, **b16)
         else:
-            dx = torch.zeros(M, d, **f32); dxb = torch.zeros(M, d, **b16)
+            dx = torch.zeros(M, d, **gx); dxb = torch.zeros(M, d, **b16)
         dense = {} if want_dense else None
         ones8 = torch.ones(M, 8, **b16) if want_dense else None
 
@@ -546,7 +550,7 @@ class Engine:
         dxb2 = [dxb, torch.empty(M, d, **b16)]
         dh = torch.empty(M, d, **b16); do = torch.empty(M, d, **b16)
         delta = torch.empty(n_img, heads, S, **f32)
-        dxm = torch.empty(M, d, **f32)
+        dxm = torch.empty(M, d, **gx)
         weT = lambda l, nm: lay.weff(self._weff, l, nm, transposed=True)
         rg_full, rg_cls = st['rg_full'], st['rg_cls']
         main = torch.cuda.current_stream(dev)
@@ -570,7 +574,7 @@ class Engine:
         if prune:
             cls_tmp = dict(U2=torch.empty(n_img, Rp, **b16), U1=torch.empty(n_img, Rp, **b16), Uo=torch.empty(n_img, Rp, **b16),
                            du=torch.empty(n_img, ff, **b16), dh=torch.empty(n_img, d, **b16), do=torch.empty(n_img, d, **b16),
-                           dxm=torch.empty(n_img, d, **f32), dxmb=torch.empty(n_img, d, **b16))
+                           dxm=torch.empty(n_img, d, **gx), dxmb=torch.empty(n_img, d, **b16))
 
         def lora_grads(l, calls):
             """Adapter gradients of one linear on the side stream: U = mask(dY . Bcat) * (alpha/r), dB += dY^T T, dA += U^T X.
@@ -684,6 +688,7 @@ class Engine:
             # embedded sequence x0[img, t] = (cls | patch_t) + pos[t]: dx now holds d loss / d x0
             ones_r = torch.ones(1, n_img, **f32)
             dpos = torch.empty(1, S * d, **f32)
+            dx = dx.float()
             ops.sgemm(ones_r, dx.view(n_img, S * d), dpos)
             dpos = dpos.view(S, d)
             dense[ce + 'vision_pos_embed'] = dpos

@@ -132,21 +132,23 @@ def ln_profile_end():
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_bf16=None, dres=None, row_index=None, dgamma=None, dbeta=None,
                   rows=None, bf16_row_scale=None, rows_per_img=0):
     rows = (row_index.shape[0] if row_index is not None else x.shape[0]) if rows is None else rows
+    if dres is not None and dres.dtype != dx.dtype:
+        raise ValueError('layernorm_bwd: dres and dx must have one dtype (float32 or float16)')
     if _ln_profile is not None and rows >= 4096 and row_index is None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         cols = x.shape[1]
-        # algorithmic bytes per row: dy (2 or 4) + x (4) + dres (4) + dx (4) + 16-bit copy (2)
-        nbytes = rows * cols * ((2 if dy.dtype != torch.float32 else 4) + 4 + (4 if dres is not None else 0) + 4 +
-                                (2 if dx_bf16 is not None else 0))
+        # algorithmic bytes per row: dy (2 or 4) + x (4) + dres (4 or 2) + dx (4 or 2) + 16-bit copy (2)
+        nbytes = rows * cols * ((2 if dy.dtype != torch.float32 else 4) + 4 + (dx.element_size() if dres is not None else 0) +
+                                dx.element_size() + (2 if dx_bf16 is not None else 0))
         e0.record()
         check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
-                                       ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
+                                       ptr(mean), ptr(rstd), ptr(dres), ptr(dx), L.F16 if dx.dtype == torch.float16 else L.F32, ptr(dx_bf16), dx.stride(0), ptr(dgamma),
                                        ptr(dbeta), rows, x.shape[1], ptr(bf16_row_scale), rows_per_img, stream_ptr()))
         e1.record()
         _ln_profile.append((nbytes, e0, e1))
         return
     check(lib().reid_layernorm_bwd(ptr(dy), L.dt(dy), dy.stride(0), ptr(x), x.stride(0), ptr(row_index), ptr(gamma),
-                                   ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx_bf16), dx.stride(0), ptr(dgamma),
+                                   ptr(mean), ptr(rstd), ptr(dres), ptr(dx), L.F16 if dx.dtype == torch.float16 else L.F32, ptr(dx_bf16), dx.stride(0), ptr(dgamma),
                                    ptr(dbeta), rows, x.shape[1], ptr(bf16_row_scale), rows_per_img, stream_ptr()))
 
 

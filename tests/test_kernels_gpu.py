@@ -251,6 +251,15 @@ def test_layernorm(ops, rows, cols):
     assert rel_err(dx, xr.grad + dres) < 2e-5
     assert rel_err(dgam, gr.grad) < 1e-4 and rel_err(dbet, br.grad) < 1e-4
     assert rel_err(dxb.float(), xr.grad + dres) < 1e-2
+    # the residual-stream gradient in IEEE half (dres read and dx written): one rounding of the fp32 result, saturating
+    dres_h = dres.half(); dx_h = torch.empty(rows, cols, device='cuda', dtype=torch.float16)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx_h, dx_bf16=dxb, dres=dres_h)
+    want = xr.grad + dres_h.float()
+    assert rel_err(dx_h.float(), want) < 5e-4 and (dx_h.float() - want).abs().max() <= want.abs().max() * 2.0 ** -11 * 1.01
+    ops.layernorm_bwd(dy * 1e5, x, gamma, mean, rstd, dx_h)
+    assert torch.isfinite(dx_h.float()).all() and dx_h.float().abs().max() == 65504.0
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx_h, dres=dres)
     dyb = bf(dy)
     ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dx)
     xr.grad = None
