@@ -602,7 +602,7 @@ def main():
                                'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
-    if rank == 0:
+    if rank == 0 and not args.no_kernel_events:             # (profiled runs pass --no-kernel-events: their kernel trace is of the step only)
         # the head section alone at this rank's batch and at the global batches of configs 3 / 5: under DP every rank runs it on the GLOBAL
         # batch, so (head at world * B) - (head at B) is per-rank work that data parallelism adds
         try:

@@ -420,7 +420,7 @@ namespace {
 // fast form of phase C for k <= STREAM_K_MAX (defined with the sorting helpers of the streaming section below)
 int launch_select_fast(const float* Qf, const float* Gf, int D, const int32_t* exq, const int32_t* exg, const int32_t* cand_idx,
                        const float* cand_score, const int32_t* cand_cnt, int cap, int k, int32_t* out_idx, float* out_score, int Nq,
-                       hipStream_t s);
+                       hipStream_t s, int cnt_stride = 1);
 constexpr int SELECT_FAST_K_MAX = 32;
 
 template <int BM, int BN, int WM, int WN>
@@ -434,6 +434,429 @@ int launch_filter(TopkParams p, hipStream_t s) {
     return REID_OK;
 }
 }  // namespace
+
+// ------------------------------------------------------------------------------------------ query-resident scan (<= 128 queries)
+// The reference ranks its queries one at a time or in small groups (tools/eval_mm_protocol.py:401-455); between the one-pass fp32 form
+// (<= 4 queries) and the tiled filter pass (hundreds of queries) the batched pipeline above re-stages the query panel for every gallery
+// tile and spends four launches on what is ONE pass over the 16-bit gallery.  Here (phases A and B of reid_cosine_topk in one launch):
+//   * one workgroup per compute unit owns a contiguous slice of gallery rows and streams it ONCE through LDS (LDS-DMA issued from
+//     inline assembly, 64 rows per step, the next step in flight under the current one);
+//   * the queries are MFMA operands held in REGISTERS: wave (qg, rh) keeps queries 32 qg .. 32 qg + 31 (128 VGPRs at D = 512) and scores
+//     them against the 32-row tile `rh` of every step with v_mfma_f32_32x32x16 -- a lane then owns ONE query and 16 of its scores;
+//   * no sample pass: the bar a score has to clear comes from the scan itself.  Workgroup b belongs to group b % k; every wave keeps the
+//     running maximum of each of its queries and folds it into gmax[query][group] (atomic max of an order-preserving key).  The k group
+//     maxima of a query are scores of k DISTINCT gallery rows, so their minimum B is a lower bound of the k-th best 16-bit score, and
+//     a row of the final top-k has a 16-bit score >= B - 2 eps (the margin of the filter pass: EPS_BF16 bounds |q~.g~ - q.g|).  Every
+//     wave re-reads the k values of its queries each step (through the same DMA stream; any mixture of old and new values is valid,
+//     they only grow), so the bar tightens as the whole chip scans;
+//   * steps a wave scored before all k groups had reported are scored AGAIN at the end (candidates only; their rows come from L2), so
+//     no workgroup ever waits for another one;
+//   * survivors wait in a 4-entry queue per lane in LDS and are appended to the query's candidate list with ONE returning atomic per lane
+//     at the end (or when a queue fills up).  cand_idx / cand_score / cand_cnt are those of the filter pass: phase C is unchanged.
+namespace {
+namespace scan {
+constexpr int KG = 16;            // bound groups held per query (k <= KG)
+constexpr int QCAP = 4;           // queued survivors per lane between flushes
+constexpr int NQ_MAX = 128;
+constexpr int CNT_STRIDE = 32;     // one candidate counter per 128-byte line (every workgroup of the chip adds to them at the same time)
+
+struct ScanParams {
+    const bf16_t* Q; const bf16_t* G;
+    int Nq, Ng;
+    const int32_t* exq; const int32_t* exg;
+    int k, cap;
+    uint32_t* gmax;               // [4 query groups][KG][32] keys of the group maxima; zero (= nothing yet) when the kernel starts
+    int32_t* cand_idx; float* cand_score; int32_t* cand_cnt;
+    unsigned long long* trace;    // -DREID_SCAN_TRACE builds: 8 stamps per workgroup (tools/exp_scan_trace.py)
+    int dbg;                      // -DREID_SCAN_TRACE builds: ablations (wrong results): 1 = no scoring, 2 = no publish / bar requests, 4 = no enqueue
+};
+#ifdef REID_SCAN_TRACE
+#define SCAN_TRACE(slot, v) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (slot)] = (v); } while (0)
+#else
+#define SCAN_TRACE(slot, v) do { } while (0)
+#endif
+#define SCAN_STAMP(slot) SCAN_TRACE(slot, __builtin_amdgcn_s_memrealtime())
+#ifdef REID_SCAN_TRACE
+#define SCAN_DBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define SCAN_DBG(bit) false
+#endif
+
+// order-preserving unsigned key of a float; 0 is below every float
+__device__ __forceinline__ uint32_t key_of(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key_value(uint32_t key) {
+    return key == 0 ? -INFINITY : __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+typedef __attribute__((address_space(3))) char* lds_cptr;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32ptr;
+__device__ __forceinline__ uint32_t lds_addr(const void* ptr) { return (uint32_t)(uintptr_t)(lds_cptr)(char*)ptr; }
+// LDS-DMA from inline assembly (see lora.hip dma16: hipcc then keeps no scoreboard entry for the ring and places no waits of its own)
+__device__ __forceinline__ void dma16(const void* src, uint32_t lds_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void dma16_coherent(const void* src, uint32_t lds_base) {      // sc1: past the non-coherent caches (atomics' home)
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* src, uint32_t lds_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "memory");
+}
+
+// `s_waitcnt vmcnt(n)` with a run-time, wave-uniform n (the counter completes in issue order: n = the operations allowed to stay in flight)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define REID_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        REID_VM_CASE(1) REID_VM_CASE(2) REID_VM_CASE(3) REID_VM_CASE(4) REID_VM_CASE(5) REID_VM_CASE(6) REID_VM_CASE(7) REID_VM_CASE(8)
+        REID_VM_CASE(9) REID_VM_CASE(10) REID_VM_CASE(11) REID_VM_CASE(12) REID_VM_CASE(13) REID_VM_CASE(14) REID_VM_CASE(15) REID_VM_CASE(16)
+        REID_VM_CASE(17) REID_VM_CASE(18) REID_VM_CASE(19) REID_VM_CASE(20)
+#undef REID_VM_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int KS /* D / 32 */, bool EXCL>
+__global__ __launch_bounds__(512) void scan_filter_kernel(const ScanParams p) {
+    constexpr int D = KS * 32, ROWB = D * 2, TILE_B = 32 * ROWB, CPR = ROWB / 16, RPI = 1024 / ROWB;
+    constexpr int WAVE_INSTR = (32 / RPI) / 8;            // DMA instructions per wave and tile (32 rows)
+    constexpr int NO_BAR = 0x7fffffff;
+    static_assert(RPI == 1 || RPI == 2, "D = 512 or 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tiles = smem;                                   // ring of 4 tiles of 32 rows; chunk c of row r at position c ^ (r & 15)
+    float* qsc = (float*)(smem + 4 * TILE_B);             // [512][QCAP] queued scores
+    int32_t* qix = (int32_t*)(qsc + 512 * QCAP);          // [512][QCAP] queued gallery rows (bit 31: the lane's second query)
+    uint32_t* bars = (uint32_t*)(qix + 512 * QCAP);       // [4][KG][32] this workgroup's copy of gmax
+    int32_t* exs = (int32_t*)(bars + 4 * KG * 32);        // [4][64] image ids of the rows of each ring slot
+    int* fv = (int*)(exs + 256);                          // [16] per wave: steps scored without a bar | bar complete
+    uint32_t* wgmax = (uint32_t*)(fv + 16);               // [128] keys of the workgroup's running maxima, one per query
+    int* wgcnt = (int*)(wgmax + NQ_MAX);                  // [128] survivors of the workgroup per query (final flush)
+    const uint32_t smem_lds = lds_addr(smem);             // (one cast of the array itself; LDS addresses below are offsets from it)
+    auto lds_of = [&](const void* ptr) { return smem_lds + (uint32_t)((const char*)ptr - smem); };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wave (qg, rh): queries 32 qg .. + 31 against rows 16 rh .. + 15 of EVERY tile (all eight waves work on a tile at once).  With
+    // v_mfma_f32_16x16x32 (A = 16 gallery rows, B = 16 queries) a lane owns queries qa and 16 + qa of the group and rows 4 rb .. + 3.
+    const int qg = wave & 3, rh = wave >> 2;
+    const int qa = lane & 15, rb = lane >> 4;
+    const bool active = qg < ((p.Nq + 31) >> 5);
+    int qv[2];
+    bool qk[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) { qv[jb] = qg * 32 + jb * 16 + qa; qk[jb] = active && qv[jb] < p.Nq; }
+    // step i of workgroup b covers the 64-row chunk i * gridDim.x + b (two tiles): at any moment the chip reads one contiguous window
+    const int n_chunks = (p.Ng + 63) >> 6;
+    if ((int)blockIdx.x >= n_chunks) return;
+    const int nstep = (n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ntile = 2 * nstep;
+    const int row_end = p.Ng;
+    auto tile_row0 = [&](int t) { return ((t >> 1) * (int)gridDim.x + (int)blockIdx.x) * 64 + (t & 1) * 32; };
+    SCAN_STAMP(0);
+
+    auto stage = [&](int t) -> int {                      // the 32 rows of tile t -> ring slot t & 3; returns the operations issued
+        const uint32_t base = lds_of(tiles + (t & 3) * TILE_B);
+#pragma unroll
+        for (int u = 0; u < WAVE_INSTR; ++u) {
+            const int j = wave * WAVE_INSTR + u;
+            const int r = j * RPI + lane / CPR, pos = lane % CPR;
+            int gr = tile_row0(t) + r;
+            gr = gr < row_end ? gr : row_end - 1;
+            dma16(p.G + (size_t)gr * D + ((pos ^ (r & 15)) << 3), base + j * 1024);
+        }
+        if (EXCL && wave == 7) {
+            int gr = tile_row0(t) + (lane & 31);
+            gr = gr < row_end ? gr : row_end - 1;
+            dma4(p.exg + gr, lds_of(exs + (t & 3) * 64));
+            return WAVE_INSTR + 1;
+        }
+        return WAVE_INSTR;
+    };
+    // three tiles in flight before anything else (the query loads below overlap them)
+    int a2 = 0, a1 = 0;
+    stage(0);
+    if (ntile > 1) a2 = stage(1);
+    if (ntile > 2) a1 = stage(2);
+    for (int i = tid; i < 4 * KG * 32; i += 512) bars[i] = 0;
+    if (tid < NQ_MAX) { wgmax[tid] = 0; wgcnt[tid] = 0; }
+
+    bf16x8 bq[2][KS];                                     // the wave's 32 queries as B operands
+    int eq[2] = {-1, -1};
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        const bf16_t* qp = p.Q + (size_t)(qk[jb] ? qv[jb] : 0) * D + rb * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bq[jb][ks] = *(const bf16x8*)(qp + ks * 32);
+            if (!qk[jb]) bq[jb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (EXCL && qk[jb]) eq[jb] = p.exq[qv[jb]];
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[jb][ks]));   // the loads above are waited for HERE, not inside the loop
+        asm volatile("" : "+v"(eq[jb]));
+    }
+    uint32_t* my_gmax = p.gmax + ((size_t)qg * KG + (blockIdx.x % p.k)) * 32 + (lane & 31);   // lanes 0..31 of the rh = 0 wave: one query each
+    const float margin = 2.f * EPS_BF16;
+
+    auto request_bars = [&]() {                           // this query group's KG x 32 keys (2 KiB), past the non-coherent caches
+#pragma unroll
+        for (int u = 0; u < KG * 32 * 4 / 1024; ++u)
+            dma16_coherent((const char*)(p.gmax + (size_t)qg * KG * 32) + u * 1024 + lane * 16, lds_of(bars + qg * KG * 32) + u * 1024);
+    };
+    constexpr int BAR_INSTR = KG * 32 * 4 / 1024;
+
+    // chunk 4 ks + rb of row 16 rh + qa sits at position (4 ks + rb) ^ qa: four per-lane offsets (ks & 3) + an immediate (ks >> 2)
+    int aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[j] = (rh * 16 + qa) * ROWB + (((4 * j + rb) ^ qa) << 4);
+    float mx[2] = {-INFINITY, -INFINITY}, mx_loc[2] = {-INFINITY, -INFINITY}, bar[2] = {INFINITY, INFINITY};
+    uint32_t pub_key = 0;
+    bool valid = false;                                   // (wave-uniform) every group of every query of this wave has reported
+    int first_valid = NO_BAR;
+    int qn = 0;
+
+    auto flush = [&]() {                                  // queued survivors -> the queries' candidate lists
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            int n = 0;
+            for (int j = 0; j < qn && j < QCAP; ++j) n += ((qix[tid * QCAP + j] >> 31) & 1) == jb ? 1 : 0;
+            if (n > 0) {
+                int slot = atomicAdd(p.cand_cnt + qv[jb] * CNT_STRIDE, n);
+                for (int j = 0; j < qn && j < QCAP; ++j) {
+                    const int e = qix[tid * QCAP + j];
+                    if (((e >> 31) & 1) != jb) continue;
+                    if (slot < p.cap) {
+                        p.cand_idx[(size_t)qv[jb] * p.cap + slot] = e & 0x7fffffff;
+                        p.cand_score[(size_t)qv[jb] * p.cap + slot] = qsc[tid * QCAP + j];
+                    }
+                    ++slot;
+                }
+            }
+        }
+        qn = 0;
+    };
+    auto read_bars = [&]() {
+        bool ok = true;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            float b = INFINITY;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const float v = key_value(bars[(qg * KG + g) * 32 + jb * 16 + qa]);
+                b = g < p.k ? fminf(b, v) : b;
+            }
+            ok = ok && (!qk[jb] || b > -INFINITY);
+            bar[jb] = qk[jb] ? b - margin : INFINITY;
+        }
+        valid = __ballot(ok) == ~0ull;
+    };
+    // the wave's 16 rows of tile t against its 32 queries; track: fold into the running maxima; enqueue: compare with the bars
+    auto score_tile = [&](int t, bool track, bool enqueue) {
+        const char* tile = tiles + (t & 3) * TILE_B;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        bf16x8 a[2][4];                                   // fragments are read four k-steps ahead of their use
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[0][u] = *(const bf16x8*)(tile + aoff[u]);
+#pragma unroll
+        for (int g = 0; g < KS / 4; ++g) {
+            if (g + 1 < KS / 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[(g + 1) & 1][u] = *(const bf16x8*)(tile + aoff[u] + (g + 1) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);            // (hipcc otherwise sinks every read to just before its MFMA: one LDS latency per MFMA)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma16(a[g & 1][u], bq[0][4 * g + u], acc[0]);
+                acc[1] = mfma16(a[g & 1][u], bq[1][4 * g + u], acc[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int trow0 = tile_row0(t) + rh * 16 + rb * 4;  // element e of a lane: row trow0 + e
+        if (trow0 + 4 > row_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (trow0 + e >= row_end) { acc[0][e] = -INFINITY; acc[1][e] = -INFINITY; }
+        }
+        if (EXCL) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const i32x4 ids = *(const i32x4*)(exs + (t & 3) * 64 + rh * 16 + rb * 4);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (eq[jb] >= 0 && ids[e] == eq[jb]) acc[jb][e] = -INFINITY;
+        }
+        float m[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            m[jb] = fmaxf(fmaxf(acc[jb][0], acc[jb][1]), fmaxf(acc[jb][2], acc[jb][3]));
+            if (track) mx[jb] = fmaxf(mx[jb], m[jb]);
+        }
+        if (enqueue && __ballot(m[0] >= bar[0] || m[1] >= bar[1]) != 0) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool hit = acc[jb][e] >= bar[jb];
+                    if (__ballot(hit && qn >= QCAP) != 0) flush();
+                    if (hit) {
+                        qsc[tid * QCAP + qn] = acc[jb][e];
+                        qix[tid * QCAP + qn] = (int32_t)((uint32_t)(trow0 + e) | ((uint32_t)jb << 31));
+                        ++qn;
+                    }
+                }
+        }
+    };
+    // running maxima: lane -> workgroup (LDS atomic max, only when a lane's maximum moved) -> chip (one lane per query and workgroup)
+    auto fold_local = [&]() {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const bool up = qk[jb] && mx[jb] > mx_loc[jb];
+            if (__ballot(up) == 0) continue;
+            if (up) __hip_atomic_fetch_max((lds_u32ptr)wgmax + qv[jb], key_of(mx[jb]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            mx_loc[jb] = mx[jb];
+        }
+    };
+    auto publish = [&]() -> int {                         // (rh = 0 waves) returns the operations issued (wave-uniform)
+        const uint32_t key = wgmax[qg * 32 + (lane & 31)];
+        const bool up = lane < 32 && qg * 32 + lane < p.Nq && key > pub_key;
+        if (__ballot(up) == 0) return 0;
+        if (up) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(my_gmax), "v"(key) : "memory");   // sc1: agent scope (the XCDs' L2s are not coherent)
+        pub_key = key > pub_key ? key : pub_key;
+        return 1;
+    };
+    // The group maxima are published after steps 0, 1 and every fourth step, and re-read after steps 0, 1, 3, 7 and then every eighth
+    // step, the reads staggered over the workgroups (every step while the bar is incomplete).  The 2 KiB a query group reads are the SAME
+    // lines for every workgroup of the chip, served past the L2s, and so are the atomics' targets: with every wave publishing its own
+    // maxima and re-reading every step this traffic, not the gallery, set the pace (120 us at 128 queries against 44 us without it;
+    // 34 us = the bare stream).  A request is issued at the end of step i and consumed at the start of step i + 2: by then it has landed
+    // with the tile that was staged just before it, and nothing waits for the atomics behind it.
+    auto refresh_after = [&](int i) { return i == 0 || i == 1 || i == 3 || i == 7 || (i > 7 && ((i + (int)blockIdx.x) & 7) == 7); };
+    auto publish_after = [&](int i) { return i == 0 || i == 1 || (i & 3) == 3 || i + 1 == nstep; };
+
+    __syncthreads();                                      // (bars, wgmax zeroed)
+    SCAN_STAMP(1);
+    // Operations in flight per wave, in issue order: A(t-3) = tile t .. R(t-3), P(t-3), A(t-2), .., A(t-1), R(t-1), P(t-1) with A = the stage
+    // at the top of an iteration, R = the bar request and P = the atomic of its tail.  Tile t has landed when at most R(t-3) + P(t-3) +
+    // A(t-2) + ... + P(t-1) operations are left, the request R(t-3) when at most P(t-3) + A(t-2) + ... are.
+    int r3 = 0, p3 = 0, r2 = 0, p2 = 0, r1 = 0, p1 = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int i = t >> 1;
+        // the bars requested after tile t - 3 (the last tile of step i - 2, by the rh = 0 waves) are read at tile t = 2 i by both halves
+        const bool read_due = active && (t & 1) == 0 && i > 1 && (first_valid == NO_BAR || refresh_after(i - 2));
+        wait_vm((read_due ? 0 : r3) + p3 + a2 + r2 + p2 + a1 + r1 + p1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t == 2) SCAN_STAMP(7);
+        const int a0 = t + 3 < ntile ? stage(t + 3) : 0;
+        int r0 = 0, p0 = 0;
+        if (active) {
+            if (read_due) {
+                read_bars();
+                if (valid && first_valid == NO_BAR) first_valid = i;
+            }
+            if (!SCAN_DBG(1)) {
+                score_tile(t, true, valid && !SCAN_DBG(4));
+                fold_local();
+            }
+            if ((t & 1) == 1 && rh == 0 && !SCAN_DBG(2)) {       // end of step i
+                if (first_valid == NO_BAR || refresh_after(i)) { request_bars(); r0 = BAR_INSTR; }
+                if (first_valid == NO_BAR || publish_after(i)) p0 = publish();
+            }
+        }
+        r3 = r2; p3 = p2; a2 = a1; r2 = r1; p2 = p1; a1 = a0; r1 = r0; p1 = p0;
+    }
+    SCAN_STAMP(2);
+    int polls = 0;
+    // Tail.  A workgroup that is through before every group has reported (short scans: all workgroups finish together) polls a bounded
+    // number of times -- it never depends on another workgroup to terminate.
+    for (int poll = 0;; ++poll) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active) read_bars();
+        if (lane == 0) fv[8 + wave] = (!active || valid) ? 1 : 0;
+        __syncthreads();
+        bool all = true;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) all = all && fv[8 + w] != 0;
+        polls = poll;
+        if (all || poll >= 64) break;
+        if (active && rh == 0) request_bars();
+        __builtin_amdgcn_s_sleep(16);
+    }
+    // the steps scored without a bar, again (candidates only; their rows are in L2)
+    if (lane == 0) fv[wave] = (active && valid) ? (first_valid < nstep ? first_valid : nstep) : 0;
+    if (active && !valid) {
+        // some group of some query has still not reported (fewer scoring workgroups than k, a group whose rows are all excluded, or a chip
+        // shared with another kernel): no bar, this wave's rows were never compared, so its queries take the exact fallback (count past
+        // the capacity = the overflow mark phase C understands)
+        if (rb == 0) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+                if (qk[jb]) atomicAdd(p.cand_cnt + qv[jb] * CNT_STRIDE, p.cap + 1);
+        }
+    }
+    __syncthreads();
+    int nrev = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) nrev = fv[w] > nrev ? fv[w] : nrev;
+    SCAN_STAMP(3);
+    SCAN_TRACE(6, (unsigned long long)polls | ((unsigned long long)nrev << 16) | ((unsigned long long)(first_valid & 0xffff) << 32));
+    (void)polls;
+    for (int t0 = 0; t0 < 2 * nrev; t0 += 4) {            // four tiles per round trip
+        if (t0 > 0) __syncthreads();
+        for (int u = 0; u < 4 && t0 + u < 2 * nrev; ++u) stage(t0 + u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int u = 0; u < 4 && t0 + u < 2 * nrev; ++u) {
+            const int t = t0 + u;
+            if (active && valid && (t >> 1) < first_valid) score_tile(t, false, true);
+        }
+    }
+    SCAN_STAMP(4);
+    // Final flush: the lanes of the workgroup first reserve their places in LDS, then ONE lane per query adds the workgroup's total to the
+    // query's counter (each lane adding for itself: ~50 k lane-atomics of the whole chip on the same few lines at the same moment, 12 us
+    // median / 26 us worst per workgroup), and the entries are written behind the returned base.
+    int off[2] = {0, 0};
+    if (active) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            int n = 0;
+            for (int j = 0; j < qn && j < QCAP; ++j) n += ((qix[tid * QCAP + j] >> 31) & 1) == jb ? 1 : 0;
+            if (n > 0) off[jb] = __hip_atomic_fetch_add((lds_u32ptr)wgcnt + qv[jb], (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    int* wgbase = (int*)bars;                             // (the bars are no longer needed)
+    if (tid < NQ_MAX) wgbase[tid] = wgcnt[tid] > 0 ? atomicAdd(p.cand_cnt + tid * CNT_STRIDE, wgcnt[tid]) : 0;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            int slot = wgbase[qv[jb] & (NQ_MAX - 1)] + off[jb];
+            for (int j = 0; j < qn && j < QCAP; ++j) {
+                const int e = qix[tid * QCAP + j];
+                if (((e >> 31) & 1) != jb) continue;
+                if (slot < p.cap) {
+                    p.cand_idx[(size_t)qv[jb] * p.cap + slot] = e & 0x7fffffff;
+                    p.cand_score[(size_t)qv[jb] * p.cap + slot] = qsc[tid * QCAP + j];
+                }
+                ++slot;
+            }
+        }
+    }
+    SCAN_STAMP(5);
+}
+#ifdef REID_SCAN_TRACE
+unsigned long long* g_scan_trace = nullptr;
+#endif
+}  // namespace scan
+}  // namespace
+#ifdef REID_SCAN_TRACE
+extern "C" void reid_debug_scan_trace(void* buf) { scan::g_scan_trace = (unsigned long long*)buf; }
+#endif
 
 extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf, int32_t Nq, int32_t Ng,
                                 int32_t D, int32_t k, const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
@@ -454,6 +877,36 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     using C = Cfg<BM, BN, 2, 2>;
     REID_MAX_LDS((score_kernel<BM, BN, 2, 2, true>), C::LDS_BYTES);
     REID_MAX_LDS((score_kernel<BM, BN, 2, 2, false>), C::LDS_BYTES);
+    // <= 128 queries: phases A and B as ONE pass of the query-resident scan kernel (scan::scan_filter_kernel); REID_TOPK_SCAN=0: the tiled form
+    if (Nq <= scan::NQ_MAX && k <= scan::KG && k <= SELECT_FAST_K_MAX && (D == 512 || D == 256) && reid_knob(KNOB_TOPK_SCAN) != 0) {
+        int cus = reid_num_cus() & ~7;
+        if (cus < 8) cus = 8;
+        const int n_chunks = (Ng + 63) / 64;
+        const int grid = n_chunks < cus ? n_chunks : cus;       // one workgroup per compute unit, 64-row chunks dealt round-robin
+        const size_t scan_ws = (size_t)(scan::NQ_MAX * scan::CNT_STRIDE + 4 * scan::KG * 32) * sizeof(int32_t);   // inside the sample area of ws
+        if (grid >= 4 * k && (size_t)Nq * ns * sizeof(float) >= scan_ws) {
+            // cnt2[128 x CNT_STRIDE] | gmax[4][KG][32] live in the (unused) sample area: one fill
+            int32_t* cnt2 = (int32_t*)dense;
+            uint32_t* gmax = (uint32_t*)(cnt2 + scan::NQ_MAX * scan::CNT_STRIDE);
+            REID_CHECK_HIP(hipMemsetAsync(cnt2, 0, (scan::NQ_MAX * scan::CNT_STRIDE + 4 * scan::KG * 32) * sizeof(int32_t), s), "hipMemsetAsync");
+            scan::ScanParams sp{};
+            sp.Q = (const bf16_t*)Q_bf16; sp.G = (const bf16_t*)G_bf16; sp.Nq = Nq; sp.Ng = Ng; sp.exq = exclude_q; sp.exg = exclude_g;
+            sp.k = k; sp.cap = cap; sp.gmax = gmax; sp.cand_idx = cidx; sp.cand_score = cscore; sp.cand_cnt = cnt2;
+#ifdef REID_SCAN_TRACE
+            sp.trace = scan::g_scan_trace;
+            sp.dbg = getenv("REID_SCAN_DBG") ? atoi(getenv("REID_SCAN_DBG")) : 0;
+#endif
+#define REID_SCAN_LAUNCH(KS, EX) do {                                                                                           \
+            constexpr size_t lds = 4 * 32 * (KS * 64) + 512 * scan::QCAP * 8 + 4 * scan::KG * 32 * 4 + 1024 + 64 + 1024;                \
+            REID_MAX_LDS((scan::scan_filter_kernel<KS, EX>), lds);                                                              \
+            hipLaunchKernelGGL((scan::scan_filter_kernel<KS, EX>), dim3(grid), dim3(512), lds, s, sp); } while (0)
+            if (D == 512) { if (exclude_q) REID_SCAN_LAUNCH(16, true); else REID_SCAN_LAUNCH(16, false); }
+            else { if (exclude_q) REID_SCAN_LAUNCH(8, true); else REID_SCAN_LAUNCH(8, false); }
+#undef REID_SCAN_LAUNCH
+            REID_CHECK_LAUNCH("reid_cosine_topk(scan)");
+            return launch_select_fast(Qf, Gf, D, exclude_q, exclude_g, cidx, cscore, cnt2, cap, k, out_idx, out_score, Nq, s, scan::CNT_STRIDE);
+        }
+    }
     TopkParams p{};
     p.Q = (const bf16_t*)Q_bf16; p.G = (const bf16_t*)G_bf16; p.Nq = Nq; p.Ng = Ng; p.D = D;
     p.exq = exclude_q; p.exg = exclude_g; p.cap = cap;
@@ -862,7 +1315,7 @@ __global__ __launch_bounds__(256) void select_fast_kernel(const float* __restric
                                                           const int32_t* __restrict__ exq, const int32_t* __restrict__ exg,
                                                           const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_score,
                                                           const int32_t* __restrict__ cand_cnt, int cap, int k,
-                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_score, int Nq) {
+                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_score, int Nq, int cnt_stride) {
     extern __shared__ __attribute__((aligned(16))) char smf[];
     float* sc = (float*)smf;                               // [cap] 16-bit-operand scores of the candidates
     float* qrow = sc + ((cap + 3) & ~3);                   // [D], 16-byte aligned
@@ -875,7 +1328,7 @@ __global__ __launch_bounds__(256) void select_fast_kernel(const float* __restric
     __shared__ float thr2;
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int cnt = cand_cnt[q];
+    const int cnt = cand_cnt[(size_t)q * cnt_stride];
     if (cnt > cap) {                                       // overflow: caller takes the exact fallback
         if (tid == 0) { out_idx[(size_t)q * k] = -2; out_score[(size_t)q * k] = 0.f; }
         return;
@@ -952,11 +1405,11 @@ __global__ __launch_bounds__(256) void select_fast_kernel(const float* __restric
 
 int launch_select_fast(const float* Qf, const float* Gf, int D, const int32_t* exq, const int32_t* exg, const int32_t* cand_idx,
                        const float* cand_score, const int32_t* cand_cnt, int cap, int k, int32_t* out_idx, float* out_score, int Nq,
-                       hipStream_t s) {
+                       hipStream_t s, int cnt_stride) {
     const size_t lds = (size_t)((cap + 3) & ~3) * 4 + (size_t)D * 4 + 512 * 8 + (size_t)SELECT_SV * 12;
     REID_MAX_LDS((select_fast_kernel), 8192 * 4 + 1024 * 4 + 512 * 8 + SELECT_SV * 12);
     hipLaunchKernelGGL(select_fast_kernel, dim3(Nq), dim3(256), lds, s, Qf, Gf, D, exq, exg, cand_idx, cand_score, cand_cnt, cap, k, out_idx,
-                       out_score, Nq);
+                       out_score, Nq, cnt_stride);
     REID_CHECK_LAUNCH("reid_cosine_topk(select)");
     return REID_OK;
 }

@@ -21,7 +21,7 @@ extern "C" int reid_version(void) { return 200; }
 static const char* const g_knob_names[] = {
     "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM", "GEMM_EPI", "GEMM_STAGGER",
     "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "STREAM_GROUPS", "SDM_IMPL", "SKINNY_TILE", "GEMM_PERSIST",
-    "ATTN_BWD", "LORA_IMPL", "GELU_IMPL", "HEAD_IMPL", "STREAM_FUSE"};
+    "ATTN_BWD", "LORA_IMPL", "GELU_IMPL", "HEAD_IMPL", "STREAM_FUSE", "TOPK_SCAN"};
 static_assert(sizeof(g_knob_names) / sizeof(g_knob_names[0]) == KNOB_COUNT, "one name per reid_knob_id");
 static int g_knobs[KNOB_COUNT];
 static bool knob_is_debug(int i) { return i == KNOB_GEMM_DBG || i == KNOB_ATTN_DBG || i == KNOB_TOPK_DBG; }

@@ -710,6 +710,51 @@ def test_cosine_topk_fast_select_equals_first_form(ops, Nq, Ng, D, k):
         assert res[0][0][0, :3].tolist() == [3, 5, 17]
 
 
+@pytest.mark.parametrize('Nq,Ng,D,k,dups', [(5, 70037, 512, 10, 0), (33, 65536 + 64, 512, 10, 3), (128, 200000, 512, 10, 0), (97, 131072 + 1, 256, 16, 3),
+                                             (128, 81920, 512, 1, 0), (64, 70000, 512, 10, 4000)])
+def test_cosine_topk_query_resident_scan_equals_tiled_filter(ops, Nq, Ng, D, k, dups):
+    """<= 128 queries take the query-resident scan (scan::scan_filter_kernel: the 16-bit gallery streamed once through LDS, the queries as
+    MFMA operands in registers, the bar of each query from the running group maxima of the scan itself) in place of the sample +
+    threshold + tiled filter launches (knob TOPK_SCAN=0).  Same candidate-list contract, so the final lists and fp32 score bits must be
+    identical: ragged last workgroup / last tile, planted exact ties, same-image exclusions that remove the best rows, near-duplicate
+    clusters (dups: copies of the best row + 1e-4 noise; 4000 of them overflow the candidate list -> exact fallback through GalleryIndex),
+    a query with an id nobody shares, k = 1 and k = 16 (= the kernel's group limit)."""
+    from prcv2025reid_amd import _lib
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    g = torch.Generator(device='cuda').manual_seed(Nq * 11 + k + dups)
+    Q = torch.nn.functional.normalize(torch.randn(Nq, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    G[5] = G[3]; G[Ng - 1] = G[3]; Q[0] = G[3]                                   # exact ties, one of them in the ragged tail
+    if dups:
+        where = torch.randint(0, Ng, (dups,), device='cuda', generator=g)
+        G[where] = torch.nn.functional.normalize(Q[2].view(1, -1) + 1e-4 * torch.randn(dups, D, device='cuda', generator=g), dim=1)
+    gid = torch.full((Ng,), -1, device='cuda', dtype=torch.int32); qid = torch.full((Nq,), -1, device='cuda', dtype=torch.int32)
+    sim0 = Q[1].double() @ G.double().t()
+    gid[torch.topk(sim0, 3).indices] = 7; qid[1] = 7                             # the three best rows of query 1 are its own image
+    gid[torch.randint(0, Ng, (200,), device='cuda', generator=g)] = 9; qid[Nq - 1] = 11
+    index = GalleryIndex(G, normalized=True, img_ids=gid)
+    res = []
+    try:
+        for knob in (-1, 0):
+            _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', knob))
+            res.append(index.topk(Q, k=k, normalized=True, query_img_ids=qid, stream=False))
+            res.append(index.topk(Q, k=k, normalized=True, stream=False))                     # (the kernel without exclusions)
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', -1))
+    for a, b in ((0, 2), (1, 3)):
+        assert int((res[a][0] < -1).sum()) == 0
+        assert torch.equal(res[a][0], res[b][0])
+        assert torch.equal(res[a][1].view(torch.int32), res[b][1].view(torch.int32))
+    if k >= 3 and not dups:
+        assert res[1][0][0, :3].tolist() == [3, 5, Ng - 1]
+    sim = Q.double() @ G.double().t()
+    for r_, masked in ((res[0], True), (res[1], False)):
+        sm = sim.masked_fill((qid.view(-1, 1) >= 0) & (qid.view(-1, 1) == gid.view(1, -1)), -1e9) if masked else sim
+        ref = torch.argsort(sm.float(), dim=1, descending=True, stable=True)[:, :k]
+        for qi, r in (ref != r_[0].long()).nonzero().tolist():                               # only fp32-rounding near-ties may differ
+            assert abs(float(sm[qi, int(ref[qi, r])] - sm[qi, int(r_[0][qi, r])])) < 2e-7, (qi, r)
+
+
 @pytest.mark.parametrize('Nq,Ng,D,k', [(1, 5000, 512, 10), (3, 20001, 512, 10), (4, 777, 256, 32), (3, 13, 512, 10), (2, 4096, 1024, 1),
                                         (4, 100000, 512, 10)])
 def test_cosine_topk_stream_equals_batched_path(ops, Nq, Ng, D, k):
