@@ -34,6 +34,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_m;  // row tiles per L2 group of the tile order (gemm_core.h tile_coords)
     int stagger;  // ping-pong kernel: spread (in 0.25 us units) of the start times of the first round of workgroups
+    int aux_pre;  // multiply-by-derivative epilogue on the 256-row tile: aux tile staged inside the K loop (REID_GELU_IMPL=1: after it, the r03 form)
     int perm_b;   // weight rows staged through perm32() (16-bit C with 16-byte pieces)
     int dbg;      // timing experiments only (REID_GEMM_DBG): 1 = skip the epilogue, 4 = skip the K loop (epilogue only)
     int epi;      // EPI_*: which epilogue the kernel instance was built with (host side choice)
@@ -502,11 +503,27 @@ __global__ __launch_bounds__(512, 2) void mer_gemm_pp_kernel(const GemmParams p)
         if (acc[0][0][0] != 1234.5f) return;
     }
 #endif
-    if (REID_DBG(p) != 4)
-        mainloop_pp<BM, 256>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0);
+    // multiply-by-derivative epilogue on the 256-row tile: the aux tile is staged by the K loop's last two steps (gemm_core.h AUXPRE)
+    constexpr bool AUX_IN_LOOP = EPI == EPI_MULAUX && BM == 256;
+    const bool aux_staged = AUX_IN_LOOP && p.aux_pre != 0 && p.K2 == 0 && (p.K >> 6) >= 2 && REID_DBG(p) != 4;
+    if (REID_DBG(p) != 4) {
+        mainloop_pp<BM, 256, 0, AUX_IN_LOOP>(p.A, p.lda, Bw, p.ldb, A2, p.lda2, p.B2, p.ldb2, m_end, p.N, p.K, p.K2, m0, n0, smem, acc, p.perm_b != 0,
+                                             aux_staged ? (const bf16_t*)p.aux : nullptr, p.ldaux);
+    }
     GEMM_TRACE(1);
     if (REID_DBG(p) == 1) return;
     if constexpr (EPI == EPI_MULAUX) {
+        if (aux_staged) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            store_tile_fast<TM, 4, EPI>(p, acc, m0 + wm * RW, n0 + wn * 64, lane, m_end, smem, wm * RW, wn * 8);
+            GEMM_TRACE(2);
+#ifdef REID_GEMM_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GEMM_TRACE(3);
+#endif
+            return;
+        }
         // The saved-derivative tile (256 rows x 512 B) comes in through LDS, which the K loop has just left: 128 LDS-DMA instructions
         // of two 512-byte row segments each, instead of 128 register loads of sixteen 64-byte row segments -- the register-direct form
         // kept a workgroup 8.5 us in this epilogue (per-workgroup trace, tools/exp_gemm_trace.py), most of it waiting for those reads.
@@ -639,6 +656,7 @@ int launch_pp(GemmParams& p, hipStream_t s, int tile_knob) {
     p.tiles_m = row_tiles(p, bm, true);
     p.tiles_n = (p.N + 255) / 256;
     p.stagger = reid_knob(KNOB_GEMM_STAGGER) > 0 ? reid_knob(KNOB_GEMM_STAGGER) : 0;
+    p.aux_pre = reid_knob(KNOB_GELU_IMPL) != 1;
 #ifdef REID_GEMM_TRACE
     p.trace = g_gemm_trace;
 #endif

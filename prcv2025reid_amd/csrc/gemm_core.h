@@ -219,10 +219,16 @@ __device__ __forceinline__ void pp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)
 __device__ __forceinline__ void pp_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ABL (timing experiments only, results are wrong): bit 0 = no LDS-DMA in the loop, 1 = no fragment reads, 2 = no MFMAs, 3 = no barriers
-template <int BM, int BN, int ABL = 0>
+// AUXPRE (256-row tile, aux != null): the epilogue's [256 rows x 512 B] tile of a second operand (the saved GELU derivative of the
+// multiply-by-derivative epilogue) rides in on the LAST TWO K-tiles' staging slots -- where K-tiles nk and nk + 1 would be staged -- so it
+// lands under the last MFMAs instead of after the loop: rows 128 b + .. of the tile go to buffer b as the image the epilogue reads
+// (row r at r * 512, chunk c at position c ^ (r & 15)), the weight halves' slots taking rows 64..127 and each wave row's own activation
+// slot rows 32 wm .. + 31, with the instruction counts of the steady state (the counted waits stay as they are).  Needs nk >= 2.
+template <int BM, int BN, int ABL = 0, bool AUXPRE = false>
 __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                             const bf16_t* __restrict__ A2, int lda2, const bf16_t* __restrict__ B2, int ldb2,
-                                            int M, int N, int K, int K2, int m0, int n0, char* smem, f32x4 (&acc)[4][PPCfg<BM, BN>::TM], bool perm_b) {
+                                            int M, int N, int K, int K2, int m0, int n0, char* smem, f32x4 (&acc)[4][PPCfg<BM, BN>::TM], bool perm_b,
+                                            const bf16_t* __restrict__ aux = nullptr, int ldaux = 0) {
     using C = PPCfg<BM, BN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -305,6 +311,26 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + buf * C::BUF_BYTES + (2 + h) * C::HALF_BYTES + (j * 8 + wave) * 8 * 128), 16, 0, 0);
             }
     };
+    // one LDS-DMA instruction = 1 KiB = rows 2 rp, 2 rp + 1 of the aux image
+    auto stage_aux_piece = [&](int rp, char* dst) {
+        const int row = 2 * rp + (lane >> 5), c = lane & 31;
+        const int gm = m0 + row < M ? m0 + row : M - 1;
+        const char* src = (const char*)aux + ((size_t)gm * ldaux + n0) * 2 + ((c ^ (row & 15)) << 4);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+    auto stage_aux_b = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                stage_aux_piece(buf * 64 + (2 + h) * 16 + j * 8 + wave, smem + buf * C::BUF_BYTES + (2 + h) * C::HALF_BYTES + (j * 8 + wave) * 1024);
+    };
+    auto stage_aux_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            stage_aux_piece(buf * 64 + wm * 16 + j * 4 + wn, smem + buf * C::BUF_BYTES + wm * C::HALF_BYTES + (j * 4 + wn) * 1024);
+    };
+    const bool aux_on = AUXPRE && aux != nullptr && nt >= 2;
     auto stage_a_any = [&](int t, int buf) { if (t < nk) stage_a(t, buf); else stage_a2(t, buf); };
     auto stage_b_any = [&](int t, int buf) { if (t < nk) stage_b(t, buf); else stage_b2(t, buf); };
 
@@ -374,9 +400,11 @@ __device__ __forceinline__ void mainloop_pp(const bf16_t* __restrict__ A, int ld
         half(I0{}, nks_c); bar();
         read_a(cur, 1, nks_c);
         if constexpr (FAST) { stage_b(T + 2, cur); pp_wait_vm4(); }
-        else if (T + 2 < nt) { stage_b_any(T + 2, cur); pp_wait_vm4(); } else { pp_wait_vm0(); }
+        else if (T + 2 < nt) { stage_b_any(T + 2, cur); pp_wait_vm4(); }
+        else if (AUXPRE && aux_on) { stage_aux_b(cur); pp_wait_vm4(); }
+        else { pp_wait_vm0(); }
         pp_wait_lgkm0(); bar();
-        if constexpr (FAST) stage_a(T + 2, cur); else if (T + 2 < nt) stage_a_any(T + 2, cur);
+        if constexpr (FAST) stage_a(T + 2, cur); else if (T + 2 < nt) stage_a_any(T + 2, cur); else if (AUXPRE && aux_on) stage_aux_a(cur);
         half(I1{}, nks_c); bar();
     };
 
