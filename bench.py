@@ -73,7 +73,7 @@ def parse():
     return ap.parse_args()
 
 
-PMC_FILE = 'r03_pmc_traffic.json'
+PMC_FILE = 'r04_pmc_traffic.json'
 # kernels the roofline objects are about: the committed PMC summary must have been collected on a tree that dispatches kernels of
 # these names, or the traffic figure is refused (null + a note) instead of silently describing other code
 GEMM_KERNELS = ('mer_gemm_pps_kernel', 'mer_gemm_pp_kernel', 'mer_gemm_kernel<128, 128, 2, 2')
@@ -598,7 +598,7 @@ def main():
         nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
         gbs = nb / (ms * 1e-3) / 1e9
         traffic, tnote = pmc_traffic(LN_KERNELS)
-        res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false>', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false, true> (16-bit cotangent in, residual-stream gradient in IEEE half)', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
