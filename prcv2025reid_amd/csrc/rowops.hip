@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // wave per row and the loop body runs once.
 // DX_HALF: the residual-stream gradient (dres read, dx written) in IEEE half instead of fp32: 12 instead of 16 bytes per element of
 // this HBM-bound kernel.  The caller scales the loss so that the stream sits in half's range (engine.py: loss_scaling).
-template <bool DY_BF16, bool AFFINE, bool DX_HALF>
+// VN: float4 vectors per lane (3 covers the towers' 768 columns: 78 -> 66 VGPRs = 7 waves per SIMD.  Measured r04, 50432 x 768, half dx:
+// 88.8 us at 7 waves, 90-92 us at 8 (forced: 2 spills) and at 6 -- occupancy is not what holds this kernel at 5.2 TB/s)
+template <bool DY_BF16, bool AFFINE, bool DX_HALF, int VN = MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                      const int32_t* __restrict__ row_index, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -220,17 +222,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const int lane = threadIdx.x & 63;
     const int nv = cols >> 2;
     constexpr bool affine = AFFINE;                       // (a separate instantiation: the accumulators cost the default path 5 % of its bandwidth)
-    f32x4 ag[MAXV], ab[MAXV];
+    f32x4 ag[VN], ab[VN];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
+    for (int i = 0; i < VN; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const size_t xrow = row_index ? (size_t)row_index[row] : (size_t)row;
         const float* xr = x + xrow * ldx;
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[MAXV], g[MAXV];
+        f32x4 xh[VN], g[VN];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < VN; ++i) {
             const int c = lane + i * 64;
             xh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; g[i] = xh[i];
             if (c < nv) {
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const float m1 = wave_sum(s1) / cols, m2 = wave_sum(s2) / cols;
         const float bs = bscale ? bscale[xrow / rows_per_img] : 1.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < VN; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
                 f32x4 o;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     if (affine) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < VN; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
 #pragma unroll
@@ -447,13 +449,15 @@ extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy
     hipStream_t s = (hipStream_t)stream;
     const bool aff = dgamma || dbeta;
     const bool hx = dx_dtype == REID_F16;
+#define REID_LN_BWD3(B16, AFF, HX, VN)                                                                                         \
+    hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, HX, VN>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
+                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img)
 #define REID_LN_BWD(B16, AFF)                                                                                                  \
-    do { if (hx) hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, true>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
-                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img);                       \
-         else hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, false>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
-                       (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img); } while (0)
+    do { if (hx) { if (cols <= 768) REID_LN_BWD3(B16, AFF, true, 3); else REID_LN_BWD3(B16, AFF, true, MAXV); }                 \
+         else { if (cols <= 768) REID_LN_BWD3(B16, AFF, false, 3); else REID_LN_BWD3(B16, AFF, false, MAXV); } } while (0)
     if (dy_dtype == REID_BF16) { if (aff) REID_LN_BWD(true, true); else REID_LN_BWD(true, false); }
     else { if (aff) REID_LN_BWD(false, true); else REID_LN_BWD(false, false); }
+#undef REID_LN_BWD3
 #undef REID_LN_BWD
     REID_CHECK_LAUNCH("reid_layernorm_bwd");
     return REID_OK;

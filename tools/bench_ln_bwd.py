@@ -1,0 +1,21 @@
+"""LayerNorm backward at the vision tower's size (50432 x 768), 16-bit cotangent in, residual-stream gradient in half / fp32: us per launch, TB/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from prcv2025reid_amd import ops, _lib
+rows, cols = 256 * 197, 768
+g = torch.Generator(device='cuda').manual_seed(0)
+x = torch.randn(rows, cols, device='cuda', generator=g); gam = torch.ones(cols, device='cuda')
+mean = x.mean(1); rstd = 1.0 / x.std(1)
+dy = torch.randn(rows, cols, device='cuda', generator=g).to(_lib.t16())
+dxb = torch.empty(rows, cols, device='cuda', dtype=_lib.t16())
+for dt, nb in ((torch.float16, 12), (torch.float32, 16)):
+    dres = torch.randn(rows, cols, device='cuda', generator=g).to(dt); dx = torch.empty(rows, cols, device='cuda', dtype=dt)
+    for _ in range(5): ops.layernorm_bwd(dy, x, gam, mean, rstd, dx, dx_bf16=dxb, dres=dres)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): ops.layernorm_bwd(dy, x, gam, mean, rstd, dx, dx_bf16=dxb, dres=dres)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    print(f'ln_bwd dx {str(dt):14s}: {us:6.1f} us  {rows * cols * nb / us / 1e6:5.2f} TB/s')
