@@ -307,6 +307,10 @@ int64_t reid_sdm_ws_floats(int32_t P, int32_t N, int32_t Mg, int32_t D);
  *   exclude_q/exclude_g (int32 ids, or NULL): entries with equal non-negative id get -1e9
  *   (same-image mask, eval_mm_protocol.py:421-422).
  *   out_idx int32 [Nq, k], out_score f32 [Nq, k].  ws: reid_topk_ws_bytes().
+ *   Nq <= 128 with k <= 16, D = 256 or 512 and a gallery of at least 256 k rows: the candidate filter is ONE pass of a query-resident
+ *   scan kernel (the 16-bit gallery streamed once, the queries as MFMA operands in registers, the bar of each query taken from the
+ *   scan's own running maxima) instead of the sample / threshold / tiled filter launches -- same candidate lists contract, same
+ *   results, same workspace.  A query whose candidate list overflows is marked out_idx[q, 0] = -2 for reid_cosine_topk_exact(_slots).
  * ------------------------------------------------------------------------------------------ */
 int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k);
 int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf,
