@@ -755,6 +755,33 @@ def test_cosine_topk_query_resident_scan_equals_tiled_filter(ops, Nq, Ng, D, k, 
             assert abs(float(sm[qi, int(ref[qi, r])] - sm[qi, int(r_[0][qi, r])])) < 2e-7, (qi, r)
 
 
+def test_cosine_topk_query_resident_scan_without_a_bar(ops):
+    """A query whose same-image id matches EVERY gallery row never gets a bar (none of its rows may count), and its whole 32-query wave
+    then has none: the scan marks those queries for the exact pass instead of comparing against nothing.  Result = the tiled path's."""
+    from prcv2025reid_amd import _lib
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    Nq, Ng, D, k = 40, 66000, 512, 10
+    g = torch.Generator(device='cuda').manual_seed(77)
+    Q = torch.nn.functional.normalize(torch.randn(Nq, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    gid = torch.full((Ng,), 4, device='cuda', dtype=torch.int32); qid = torch.full((Nq,), -1, device='cuda', dtype=torch.int32)
+    qid[3] = 4                                              # every row of the gallery is "the same image" as query 3
+    index = GalleryIndex(G, normalized=True, img_ids=gid)
+    res = []
+    try:
+        for knob in (-1, 0):
+            _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', knob))
+            res.append(index.topk(Q, k=k, normalized=True, query_img_ids=qid, stream=False))
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', -1))
+    assert int((res[0][0] < -1).sum()) == 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))
+    sim = Q.double() @ G.double().t()
+    ref = torch.argsort(sim.float(), dim=1, descending=True, stable=True)[:, :k]
+    ok = torch.ones(Nq, dtype=torch.bool, device='cuda'); ok[3] = False
+    assert int((ref[ok] != res[0][0][ok].long()).sum()) <= 2          # (fp32 near-ties only)
+
+
 @pytest.mark.parametrize('Nq,Ng,D,k', [(1, 5000, 512, 10), (3, 20001, 512, 10), (4, 777, 256, 32), (3, 13, 512, 10), (2, 4096, 1024, 1),
                                         (4, 100000, 512, 10)])
 def test_cosine_topk_stream_equals_batched_path(ops, Nq, Ng, D, k):
