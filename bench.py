@@ -600,7 +600,10 @@ def main():
         traffic, tnote = pmc_traffic(LN_KERNELS)
         res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false, true> (16-bit cotangent in, residual-stream gradient in IEEE half)', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
-                               'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof)}
+                               'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof),
+                               'note': 'event pairs around the launches inside the running step (the side stream shares the chip); since r04 the kernel '
+                                       'moves 12 B per element (residual-stream gradient in IEEE half) instead of 16: 90 us per launch alone against 106 '
+                                       '(rocprofv3), i.e. a shorter kernel at a lower fraction of the HBM peak'}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
     if rank == 0 and not args.no_kernel_events:             # (profiled runs pass --no-kernel-events: their kernel trace is of the step only)
         # the head section alone at this rank's batch and at the global batches of configs 3 / 5: under DP every rank runs it on the GLOBAL
