@@ -13,7 +13,7 @@ o = torch.empty(M, d, device='cuda', dtype=T16); lse = torch.empty(n_img, heads,
 do = torch.randn(M, d, device='cuda', generator=g).to(T16); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
 ops.attn_fwd(qkv, o, lse, n_img, S, heads)
 lib = _lib.lib()
-_lib.check(lib.reid_set_knob(b'ATTN_BWD', 2))
+_lib.check(lib.reid_set_knob(b'ATTN_BWD', -1))
 nwg = n_img * heads
 trace = torch.zeros(nwg, 8, dtype=torch.int64, device='cuda')
 for _ in range(3): ops.attn_bwd(qkv, o, do, lse, dqkv, delta, n_img, S, heads)
