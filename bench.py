@@ -583,6 +583,16 @@ def main():
         fl = sum(p[0] for p in prof); ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         ach = fl / (ms * 1e-3) / 1e12
         traffic, tnote = pmc_traffic(GEMM_KERNELS)
+        # what an event pair measures around NOTHING on this stream (marker-to-marker time): the part of every launch's figure that is
+        # not the kernel.  Reported beside the raw numbers, never subtracted from `achieved` / `frac`.
+        pairs = []
+        torch.cuda.synchronize()
+        for _ in range(64):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record(); pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        empty_us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)[len(pairs) // 2]
+        net_ms = max(ms - empty_us * 1e-3 * len(prof), 1e-9)
         res['roofline'] = {'kernel': 'the MER GEMM: mer_gemm_pps_kernel<EPI, BM> (persistent 256x256 / 224x256 ping-pong tiles: plain and residual epilogues), '
                                      'mer_gemm_pp_kernel<EPI, BM> (same tiles, one per workgroup: GELU / multiply-by-derivative epilogues), '
                                      'mer_gemm_kernel<128,128,2,2,EPI> (short-K narrow-N shapes); merged per-modality weights, row groups',
@@ -591,6 +601,11 @@ def main():
                            'algorithmic_bytes_per_launch_avg': sum(p[1] for p in prof) / len(prof), 'launches': len(prof),
                            'avg_launch_us': ms * 1e3 / len(prof), 'kernel_ms_per_step': ms / args.steps, 'ms_per_step_with_events': ms_with_events,
                            'flops_per_launch_avg': fl / len(prof),
+                           'empty_event_pair_us': empty_us,
+                           'frac_net_of_event_pairs': fl / (net_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                           'event_note': 'every launch is bracketed by its own event pair inside the running step; an EMPTY pair on the same stream '
+                                         'measures empty_event_pair_us, and rocprofv3 of the same command (profiles/) gives the kernels\' own durations: '
+                                         '`frac` is the raw event figure, `frac_net_of_event_pairs` the same with the empty-pair time taken off every launch',
                            'flops_counted': '2*M*N*K per launch (merged weights: no low-rank K extension, no padded columns)',
                            'clock_note': 'in-kernel shader clock under this load 1.86-1.90 GHz (profiles/r03_gemm_clock.log): the dense bf16 MFMA rate '
                                          'at that clock is 1.96 PFLOP/s; `peak` stays the 2.4 GHz figure of the microarch guide'}
