@@ -219,7 +219,8 @@ int reid_lora_da_fused(const void* X, int32_t ldx, const void* U, int32_t ldu, f
  * and its transpose -- the operands of reid_mer_gemm's row-group form.  table[e] = {W pointer (f32 [N, K] contiguous), arena
  * offset of Acat [G*Rp, K], arena offset of Bcat [N, Rp], destination offset of W_eff [nmod][N][K], destination offset of
  * W_eff^T [nmod][K][N] (negative: skip), N, K, G} (int64; offsets in elements; N, K, N/G multiples of 64; G = projections fused
- * along N, each with its own adapter rows g Rp ...).  max_tiles >= (N/64)(K/64) of every entry.  One launch per optimizer step. */
+ * along N, each with its own adapter rows g Rp ...).  max_tiles >= (N/64)(K/64) of every entry.  One launch per optimizer step.
+ * Ranks: r <= 64 per modality and nmod * r <= Rp (up to 64 adapter rows are staged at once, more one modality at a time: same results). */
 int reid_merge_lora_table(const int64_t* table, int32_t n_entries, int32_t max_tiles, const float* arena, void* weff,
                           int32_t Rp, int32_t r, int32_t nmod, float scaling, void* stream);
 /* dst[r, :] = src[index[r], :] (f32, cols % 4 == 0);  scatter_add is the adjoint. */

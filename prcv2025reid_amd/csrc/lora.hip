@@ -43,28 +43,46 @@ __global__ __launch_bounds__(256) void merge_lora_kernel(const int64_t* __restri
     __shared__ __attribute__((aligned(16))) float sA[MT][MT + 4];    // [adapter row][k]
     __shared__ __attribute__((aligned(16))) float sBt[MT][MT + 4];   // [adapter column][n]
     const int t = threadIdx.x;
+    // nmod * r <= 64: all adapter rows of the tile are staged once.  Larger ranks (r <= 64): ONE modality's rows at a time (per_mod), the
+    // same fma chains in the same order -- the results do not depend on which form ran.
+    const bool per_mod = R > MT;
     for (int i = t; i < MT * (MT / 4); i += 256) {       // 16-byte loads along k
         const int row = i / (MT / 4), c4 = (i % (MT / 4)) * 4;
         *(f32x4*)&sW[row][c4] = *(const f32x4*)(W + (size_t)(n0 + row) * K + k0 + c4);
-        if (row < R) *(f32x4*)&sA[row][c4] = *(const f32x4*)(A + (size_t)(g * Rp + row) * K + k0 + c4);
+        if (!per_mod && row < R) *(f32x4*)&sA[row][c4] = *(const f32x4*)(A + (size_t)(g * Rp + row) * K + k0 + c4);
     }
-    for (int i = t; i < MT * R; i += 256) {
-        const int row = i / R, c = i % R;
-        sBt[c][row] = B[(size_t)(n0 + row) * Rp + c];
+    if (!per_mod) {
+        for (int i = t; i < MT * R; i += 256) {
+            const int row = i / R, c = i % R;
+            sBt[c][row] = B[(size_t)(n0 + row) * Rp + c];
+        }
     }
     __syncthreads();
     const int c8 = (t & 7) * 8, r0 = t >> 3;             // a thread owns 8 consecutive elements of rows r0 and r0 + 32
     // Both passes evaluate element (n, k) of modality mu by the SAME chain: acc = fma(B[n][mu r + j], A[mu r + j][k], acc) for j = 0..r-1,
     // then fma(s, acc, W[n][k]) -- so W_eff^T is the exact transpose of W_eff.
     for (int mu = 0; mu < nmod; ++mu) {
+        if (per_mod) {
+            __syncthreads();                              // the previous modality's rows are no longer read
+            for (int i = t; i < r * (MT / 4); i += 256) {
+                const int row = i / (MT / 4), c4 = (i % (MT / 4)) * 4;
+                *(f32x4*)&sA[row][c4] = *(const f32x4*)(A + (size_t)(g * Rp + mu * r + row) * K + k0 + c4);
+            }
+            for (int i = t; i < MT * r; i += 256) {
+                const int row = i / r, c = i % r;
+                sBt[c][row] = B[(size_t)(n0 + row) * Rp + mu * r + c];
+            }
+            __syncthreads();
+        }
+        const int ab = per_mod ? 0 : mu * r;              // first staged adapter row of this modality
         bf16_t* d = dst + (size_t)mu * N * K;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int n = r0 + 32 * h;
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < r; ++j) {
-                const float b = sBt[mu * r + j][n];
-                const f32x4 a0 = *(const f32x4*)&sA[mu * r + j][c8], a1 = *(const f32x4*)&sA[mu * r + j][c8 + 4];
+                const float b = sBt[ab + j][n];
+                const f32x4 a0 = *(const f32x4*)&sA[ab + j][c8], a1 = *(const f32x4*)&sA[ab + j][c8 + 4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { acc[q] = fmaf(b, a0[q], acc[q]); acc[4 + q] = fmaf(b, a1[q], acc[4 + q]); }
             }
@@ -82,8 +100,8 @@ __global__ __launch_bounds__(256) void merge_lora_kernel(const int64_t* __restri
                 const int k = r0 + 32 * h;
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int j = 0; j < r; ++j) {
-                    const float a = sA[mu * r + j][k];
-                    const f32x4 b0 = *(const f32x4*)&sBt[mu * r + j][c8], b1 = *(const f32x4*)&sBt[mu * r + j][c8 + 4];
+                    const float a = sA[ab + j][k];
+                    const f32x4 b0 = *(const f32x4*)&sBt[ab + j][c8], b1 = *(const f32x4*)&sBt[ab + j][c8 + 4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { acc[q] = fmaf(b0[q], a, acc[q]); acc[4 + q] = fmaf(b1[q], a, acc[4 + q]); }
                 }
@@ -687,7 +705,7 @@ extern "C" int reid_merge_lora_table(const int64_t* table, int32_t n_entries, in
                                      int32_t Rp, int32_t r, int32_t nmod, float scaling, void* stream) {
     REID_CHECK_ARG(table && arena && weff, "reid_merge_lora_table: null pointer");
     REID_CHECK_ARG(n_entries > 0 && n_entries <= 65535 && max_tiles > 0, "reid_merge_lora_table: n_entries=%d max_tiles=%d", n_entries, max_tiles);
-    REID_CHECK_ARG(r > 0 && nmod > 0 && nmod * r <= MT && nmod * r <= Rp, "reid_merge_lora_table: nmod*r = %d must be <= %d and <= Rp = %d", nmod * r, MT, Rp);
+    REID_CHECK_ARG(r > 0 && nmod > 0 && r <= MT && nmod * r <= Rp, "reid_merge_lora_table: r = %d must be <= %d and nmod*r = %d <= Rp = %d", r, MT, nmod * r, Rp);
     hipLaunchKernelGGL(merge_lora_kernel, dim3(max_tiles, n_entries), dim3(256), 0, (hipStream_t)stream, table, arena, (bf16_t*)weff, Rp, r, nmod,
                        scaling);
     REID_CHECK_LAUNCH("reid_merge_lora_table");

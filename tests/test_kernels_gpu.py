@@ -1051,10 +1051,11 @@ def test_f16_conversion_saturates_finite_overflow():
         _lib.set_flavor('bf16')
 
 
-@pytest.mark.parametrize('r,G,N,K', [(8, 1, 768, 768), (4, 3, 384, 128), (16, 1, 256, 3072)])
+@pytest.mark.parametrize('r,G,N,K', [(8, 1, 768, 768), (4, 3, 384, 128), (16, 1, 256, 3072), (32, 1, 256, 768), (24, 3, 384, 128), (64, 1, 128, 128)])
 def test_merge_lora_table(ops, r, G, N, K):
     """reid_merge_lora_table: W_eff[mu] = W + s B_mu A_mu per modality (mer_lora.py:80-99 with the adapter folded into the weight),
-    rounded once to 16 bits; the transposed stack is the EXACT transpose."""
+    rounded once to 16 bits; the transposed stack is the EXACT transpose.  Ranks above 16 (nmod * r > 64: r04) stage one modality's adapter
+    rows at a time; the reference accepts any rank."""
     g = torch.Generator(device='cuda').manual_seed(r + G + N)
     nmod = 4
     Rp = ((nmod * r + 31) // 32) * 32

@@ -311,6 +311,39 @@ def test_vision_backward_random_cotangent(flavor, tol):
     print(f'  [{flavor}] worst LoRA grad rel-L2 (random cotangent) = {worst:.3e}')
 
 
+@pytest.mark.parametrize('flavor,tol', [('bf16', 4e-2), ('f16', 8e-3)])
+def test_lora_rank_32_vs_oracle(flavor, tol):
+    """LoRA rank 32 (four modalities x 32 = 128 adapter rows, Rp = 128: beyond the 64 rows the weight merge staged at once until r04; the
+    reference accepts any rank, mer_lora.py:12-38).  Encoder features and LoRA gradients under a random cotangent against autograd through
+    the oracle, on the tiny fixture's geometry with its rank replaced."""
+    from oracle import reid_oracle as O
+    z, meta = load_case('tiny_train_frozen')
+    meta = dict(meta); meta['rank'] = 32.0; meta['alpha'] = 64.0
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    model = build_model(meta, state, True, flavor)
+    g = torch.Generator().manual_seed(11)
+    imgs = {m: torch.randn(2, 3, 224, 224, generator=g) for m in ('vis', 'nir', 'sk', 'cp')}
+    R = {m: torch.randn(2, 512, generator=g) for m in imgs}
+    lora_keys = [k for k in state if '.loras.' in k]
+    for k in lora_keys:
+        if 'lora_B' in k:                               # (a zero B would leave the merged update and dA at zero)
+            state[k].copy_(0.05 * torch.randn(state[k].shape, generator=g))
+        state[k].requires_grad_(True)
+    model.load_state_dict({k: v.detach() for k, v in state.items()}, strict=True)
+    loss = sum((O.encode_vision(imgs[m], m, state, arch) * R[m]).sum() for m in imgs)
+    loss.backward()
+    from prcv2025reid_amd.engine import VisionEncodeFn
+    model.engine.refresh()
+    mods = tuple(model.vision_modalities.index(m) for m in imgs)
+    feats = VisionEncodeFn.apply(model.engine, mods, model.lora_arena, len(imgs), *[imgs[m].cuda() for m in imgs])
+    ref_feats = torch.cat([O.encode_vision(imgs[m], m, {k: v.detach() for k, v in state.items()}, arch) for m in imgs])
+    e_f = l2rel(feats.detach().cpu(), ref_feats)
+    (feats * torch.cat([R[m] for m in imgs]).cuda()).sum().backward()
+    worst = max(l2rel(model.lora_grad_view(k).cpu(), state[k].grad) for k in lora_keys)
+    print(f'  [{flavor}] rank 32: features rel-L2 {e_f:.3e}, worst LoRA grad rel-L2 {worst:.3e}')
+    assert e_f < tol / 4 and worst < tol
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # f16 operand flavor (libreid_hip_f16.so): 11 significant bits -> north_star's 1e-3 is met as stated on the encoder features, the
 # fused feature and the losses of every fixture (bounds.unit_maxabs('f16', ...) = 1e-3), and on bn_features / 8 at B = 64.
