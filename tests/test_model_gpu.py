@@ -22,6 +22,7 @@ Tolerances (oracle/bounds.py derives them; nothing here is sized to a previous r
 """
 import numpy as np
 import pytest
+from collections import OrderedDict
 import torch
 
 
@@ -309,6 +310,34 @@ def test_vision_backward_random_cotangent(flavor, tol):
         worst = max(worst, e)
         assert e < tol, (k, e)
     print(f'  [{flavor}] worst LoRA grad rel-L2 (random cotangent) = {worst:.3e}')
+
+
+@pytest.mark.parametrize('name', ['tiny_train_frozen', 'tiny_train_r16_masked', 'full_p4k2_r8_masked', 'tiny_eval'])
+def test_head_alone_on_reference_encoder_outputs(name):
+    """The head gated by ITSELF (r03 advisor: the bn_features / logits gates of the end-to-end tests are the encoder bound times a measured
+    amplification of 17-50 and say little about the head): the reference's own per-modality encoder outputs and feature masks go through
+    head_section + compute_loss of the HIP model (fp32 kernels: SDM module, fusion, BN-neck, classifier, CE, SDM); fused feature,
+    bn_features, logits and the three losses must equal the reference's to fp32 accuracy."""
+    z, meta = load_case(name)
+    cfg, arch, state, batch, tokens = case_inputs(meta)
+    training = bool(meta['training'])
+    model = build_model(meta, state, training, 'bf16')
+    kept = [str(x) for x in z['fused_modalities']]
+    raw = OrderedDict((m, torch.as_tensor(z[f'raw.{m}']).cuda()) for m in kept)
+    fmask = OrderedDict((m, torch.as_tensor(z[f'fmask.{m}']).cuda()) for m in kept)
+    with torch.set_grad_enabled(training):
+        out = model.head_section(raw, fmask)
+        e_f = float((out['features'].detach().cpu() - torch.as_tensor(z['features'])).abs().max()) / float(np.abs(z['features']).max())
+        e_b = float((out['bn_features'].detach().cpu() / 8 - torch.as_tensor(z['bn_features']) / 8).abs().max())
+        e_l = l2rel(out['logits'].detach().cpu(), z['logits'])
+        print(f'  head alone [{name}]: fused {e_f:.2e} (relative to max) | bn/8 max|delta| {e_b:.2e} | logits rel-L2 {e_l:.2e}')
+        assert e_f < 2e-5 and e_b < 2e-5 and e_l < 2e-5
+        if training:
+            L = model.compute_loss(out, batch['person_id'].cuda())
+            for k in ('total_loss', 'ce_loss', 'sdm_loss'):
+                d = abs(float(L[k].detach()) - float(z[k]))
+                print(f'    {k}: |delta| = {d:.2e}')
+                assert d < 2e-5 * max(1.0, abs(float(z[k]))), (k, d)
 
 
 @pytest.mark.parametrize('flavor,tol', [('bf16', 4e-2), ('f16', 8e-3)])
