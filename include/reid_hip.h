@@ -314,6 +314,8 @@ int64_t reid_sdm_ws_floats(int32_t P, int32_t N, int32_t Mg, int32_t D);
  *   results, same workspace.  A query whose candidate list overflows is marked out_idx[q, 0] = -2 for reid_cosine_topk_exact(_slots).
  * ------------------------------------------------------------------------------------------ */
 int64_t reid_topk_ws_bytes(int32_t Nq, int32_t Ng, int32_t k);
+/* 1 when reid_cosine_topk takes the query-resident scan for this shape (then also the faster form for 2-4 queries). */
+int32_t reid_topk_scan_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k);
 int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf,
                      int32_t Nq, int32_t Ng, int32_t D, int32_t k, const int32_t* exclude_q,
                      const int32_t* exclude_g, void* ws, int32_t* out_idx, float* out_score, void* stream);

@@ -43,7 +43,7 @@ EXPORTS = [
     'reid_eltwise_f32', 'reid_small_attn_fwd', 'reid_small_attn_bwd', 'reid_masked_mean',
     'reid_opt_entry_bytes', 'reid_opt_ws_floats', 'reid_opt_state_floats', 'reid_opt_sumsq', 'reid_opt_clip', 'reid_opt_adamw',
     'reid_rank_metrics', 'reid_scatter_add_rows_f32', 'reid_embed_tokens',
-    'reid_topk_stream_ok', 'reid_topk_stream_ws_bytes', 'reid_cosine_topk_stream', 'reid_merge_lora_table', 'reid_add_layernorm_fwd', 'reid_lora_bwd_fused', 'reid_lora_da_fused',
+    'reid_topk_stream_ok', 'reid_topk_scan_ok', 'reid_topk_stream_ws_bytes', 'reid_cosine_topk_stream', 'reid_merge_lora_table', 'reid_add_layernorm_fwd', 'reid_lora_bwd_fused', 'reid_lora_da_fused',
 ]
 
 

@@ -439,20 +439,23 @@ int launch_filter(TopkParams p, hipStream_t s) {
 // The reference ranks its queries one at a time or in small groups (tools/eval_mm_protocol.py:401-455); between the one-pass fp32 form
 // (<= 4 queries) and the tiled filter pass (hundreds of queries) the batched pipeline above re-stages the query panel for every gallery
 // tile and spends four launches on what is ONE pass over the 16-bit gallery.  Here (phases A and B of reid_cosine_topk in one launch):
-//   * one workgroup per compute unit owns a contiguous slice of gallery rows and streams it ONCE through LDS (LDS-DMA issued from
-//     inline assembly, 64 rows per step, the next step in flight under the current one);
+//   * one workgroup per compute unit; the gallery's 64-row chunks are dealt round-robin (chunk i * grid + b to workgroup b), so the chip
+//     reads one contiguous window at a time; each chunk is two 32-row tiles that pass through a ring of four LDS slots, three in flight
+//     (LDS-DMA issued from inline assembly; counted vmcnt waits with a run-time count: the bare stream runs at 6.0 TB/s);
 //   * the queries are MFMA operands held in REGISTERS: wave (qg, rh) keeps queries 32 qg .. 32 qg + 31 (128 VGPRs at D = 512) and scores
-//     them against the 32-row tile `rh` of every step with v_mfma_f32_32x32x16 -- a lane then owns ONE query and 16 of its scores;
-//   * no sample pass: the bar a score has to clear comes from the scan itself.  Workgroup b belongs to group b % k; every wave keeps the
-//     running maximum of each of its queries and folds it into gmax[query][group] (atomic max of an order-preserving key).  The k group
-//     maxima of a query are scores of k DISTINCT gallery rows, so their minimum B is a lower bound of the k-th best 16-bit score, and
-//     a row of the final top-k has a 16-bit score >= B - 2 eps (the margin of the filter pass: EPS_BF16 bounds |q~.g~ - q.g|).  Every
-//     wave re-reads the k values of its queries each step (through the same DMA stream; any mixture of old and new values is valid,
-//     they only grow), so the bar tightens as the whole chip scans;
-//   * steps a wave scored before all k groups had reported are scored AGAIN at the end (candidates only; their rows come from L2), so
-//     no workgroup ever waits for another one;
-//   * survivors wait in a 4-entry queue per lane in LDS and are appended to the query's candidate list with ONE returning atomic per lane
-//     at the end (or when a queue fills up).  cand_idx / cand_score / cand_cnt are those of the filter pass: phase C is unchanged.
+//     them against rows 16 rh .. + 15 of EVERY tile with v_mfma_f32_16x16x32 -- a lane then owns two queries and four rows of each;
+//   * no sample pass: the bar a score has to clear comes from the scan itself.  Workgroup b belongs to group b % k; the running maximum of
+//     every query is folded lane -> workgroup (LDS atomic max) -> gmax[query][group] (one agent-scope atomic max of an order-preserving key
+//     per query and workgroup, at steps 0, 1, 3, 7, ...).  The k group maxima of a query are scores of k DISTINCT gallery rows, so their
+//     minimum B is a lower bound of the k-th best 16-bit score, and a row of the final top-k has a 16-bit score >= B - 2 eps (the margin
+//     of the filter pass: EPS_BF16 bounds |q~.g~ - q.g|).  The k values are re-read through the same DMA stream (sc1: past the L2s) two
+//     steps after they were requested; any mixture of old and new values is valid, they only grow.  These lines are the SAME for every
+//     workgroup of the chip: read or updated every step by every wave they, not the gallery, set the pace;
+//   * steps a wave scored before all k groups had reported are scored AGAIN at the end (candidates only; their rows come from L2), and a
+//     workgroup that is through before the bar exists polls a bounded number of times: no workgroup depends on another one to finish;
+//   * survivors wait in a 4-entry queue per lane in LDS; at the end the lanes reserve places per workgroup and query in LDS and ONE lane
+//     per query adds the workgroup's total to the query's counter (one counter per 128-byte line).  cand_idx / cand_score / cand_cnt are
+//     those of the filter pass (cand_cnt strided): phase C is unchanged.
 namespace {
 namespace scan {
 constexpr int KG = 16;            // bound groups held per query (k <= KG)
@@ -858,6 +861,20 @@ unsigned long long* g_scan_trace = nullptr;
 extern "C" void reid_debug_scan_trace(void* buf) { scan::g_scan_trace = (unsigned long long*)buf; }
 #endif
 
+/* 1 when reid_cosine_topk takes the query-resident scan for this shape (the caller may then prefer it to the one-pass fp32 form for 2-4
+ * queries: 83-88 us against 91-105 us per call at 200k x 512, r04). */
+extern "C" int32_t reid_topk_scan_ok(int32_t Nq, int32_t Ng, int32_t D, int32_t k) {
+    if (!(Nq >= 1 && Nq <= scan::NQ_MAX && k >= 1 && k <= scan::KG && k <= SELECT_FAST_K_MAX && k <= Ng && (D == 512 || D == 256))) return 0;
+    if (reid_knob(KNOB_TOPK_SCAN) == 0) return 0;
+    int cus = reid_num_cus() & ~7;
+    if (cus < 8) cus = 8;
+    const int n_chunks = (Ng + 63) / 64;
+    const int grid = n_chunks < cus ? n_chunks : cus;
+    const int64_t ns = Ng < SAMPLE ? Ng : SAMPLE;
+    const int64_t scan_ws = (int64_t)(scan::NQ_MAX * scan::CNT_STRIDE + 4 * scan::KG * 32) * (int64_t)sizeof(int32_t);   // inside the sample area of ws
+    return grid >= 4 * k && (int64_t)Nq * ns * (int64_t)sizeof(float) >= scan_ws;
+}
+
 extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const float* Qf, const float* Gf, int32_t Nq, int32_t Ng,
                                 int32_t D, int32_t k, const int32_t* exclude_q, const int32_t* exclude_g, void* ws, int32_t* out_idx,
                                 float* out_score, void* stream) {
@@ -878,13 +895,12 @@ extern "C" int reid_cosine_topk(const void* Q_bf16, const void* G_bf16, const fl
     REID_MAX_LDS((score_kernel<BM, BN, 2, 2, true>), C::LDS_BYTES);
     REID_MAX_LDS((score_kernel<BM, BN, 2, 2, false>), C::LDS_BYTES);
     // <= 128 queries: phases A and B as ONE pass of the query-resident scan kernel (scan::scan_filter_kernel); REID_TOPK_SCAN=0: the tiled form
-    if (Nq <= scan::NQ_MAX && k <= scan::KG && k <= SELECT_FAST_K_MAX && (D == 512 || D == 256) && reid_knob(KNOB_TOPK_SCAN) != 0) {
+    if (reid_topk_scan_ok(Nq, Ng, D, k)) {
         int cus = reid_num_cus() & ~7;
         if (cus < 8) cus = 8;
         const int n_chunks = (Ng + 63) / 64;
         const int grid = n_chunks < cus ? n_chunks : cus;       // one workgroup per compute unit, 64-row chunks dealt round-robin
-        const size_t scan_ws = (size_t)(scan::NQ_MAX * scan::CNT_STRIDE + 4 * scan::KG * 32) * sizeof(int32_t);   // inside the sample area of ws
-        if (grid >= 4 * k && (size_t)Nq * ns * sizeof(float) >= scan_ws) {
+        {
             // cnt2[128 x CNT_STRIDE] | gmax[4][KG][32] live in the (unused) sample area: one fill
             int32_t* cnt2 = (int32_t*)dense;
             uint32_t* gmax = (uint32_t*)(cnt2 + scan::NQ_MAX * scan::CNT_STRIDE);

@@ -322,6 +322,10 @@ def topk_stream_ok(Nq, Ng, D, k) -> bool:
     return bool(lib().reid_topk_stream_ok(Nq, Ng, D, k))
 
 
+def topk_scan_ok(Nq, Ng, D, k):
+    return bool(lib().reid_topk_scan_ok(Nq, Ng, D, k))
+
+
 def topk_stream_ws_bytes(k):
     return int(lib().reid_topk_stream_ws_bytes(k))
 

@@ -52,7 +52,9 @@ class GalleryIndex:
         if query_img_ids is not None and self.img_ids is not None:
             exq = query_img_ids.to(Qf.device, torch.int32).contiguous(); exg = self.img_ids
         if stream is None:
-            stream = ops.topk_stream_ok(Nq, Ng, Qf.shape[1], k)
+            # one query: the one-pass fp32 form (78 us at 200k x 512); 2-4 queries: the batched entry point's query-resident scan where it
+            # applies (83-88 us against 91-105 us for the fp32 passes), else the fp32 form
+            stream = ops.topk_stream_ok(Nq, Ng, Qf.shape[1], k) and (Nq == 1 or not ops.topk_scan_ok(Nq, Ng, Qf.shape[1], k))
         if stream:
             # a handful of queries: one pass over the fp32 gallery (the reference's per-query form), no host sync
             need = ops.topk_stream_ws_bytes(k)             # (its own buffer, zero-filled once: it holds the arrival counter of the fused merge)
