@@ -18,7 +18,7 @@ __attribute__((visibility("hidden"))) void reid_set_error(const char* fmt, ...);
 enum reid_knob_id {
     KNOB_GEMM_TILE, KNOB_GEMM_DBG, KNOB_GEMM_GROUPM, KNOB_GEMM_EPI, KNOB_GEMM_STAGGER,
     KNOB_ATTN_DBG, KNOB_TN_BLOCKS, KNOB_TOPK_DBG, KNOB_TOPK_TILE, KNOB_STREAM_ROWS, KNOB_STREAM_GROUPS, KNOB_SDM_IMPL, KNOB_SKINNY_TILE, KNOB_GEMM_PERSIST,
-    KNOB_ATTN_BWD, KNOB_LORA_IMPL, KNOB_GELU_IMPL, KNOB_HEAD_IMPL, KNOB_STREAM_FUSE, KNOB_TOPK_SCAN, KNOB_COUNT
+    KNOB_ATTN_BWD, KNOB_LORA_IMPL, KNOB_GELU_IMPL, KNOB_HEAD_IMPL, KNOB_STREAM_FUSE, KNOB_TOPK_SCAN, KNOB_LN_IMPL, KNOB_COUNT
 };
 // (internal C++ symbols of the library: hidden, only the extern "C" entry points of include/reid_hip.h are exported)
 __attribute__((visibility("hidden"))) int reid_knob(int id);

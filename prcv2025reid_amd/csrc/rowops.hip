@@ -21,7 +21,7 @@ extern "C" int reid_version(void) { return 200; }
 static const char* const g_knob_names[] = {
     "GEMM_TILE", "GEMM_DBG", "GEMM_GROUPM", "GEMM_EPI", "GEMM_STAGGER",
     "ATTN_DBG", "TN_BLOCKS", "TOPK_DBG", "TOPK_TILE", "STREAM_ROWS", "STREAM_GROUPS", "SDM_IMPL", "SKINNY_TILE", "GEMM_PERSIST",
-    "ATTN_BWD", "LORA_IMPL", "GELU_IMPL", "HEAD_IMPL", "STREAM_FUSE", "TOPK_SCAN"};
+    "ATTN_BWD", "LORA_IMPL", "GELU_IMPL", "HEAD_IMPL", "STREAM_FUSE", "TOPK_SCAN", "LN_IMPL"};
 static_assert(sizeof(g_knob_names) / sizeof(g_knob_names[0]) == KNOB_COUNT, "one name per reid_knob_id");
 static int g_knobs[KNOB_COUNT];
 static bool knob_is_debug(int i) { return i == KNOB_GEMM_DBG || i == KNOB_ATTN_DBG || i == KNOB_TOPK_DBG; }
@@ -400,7 +400,71 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
     }
 }
 
+// The hot form of the towers' backward (16-bit cotangent in, residual-stream gradient in IEEE half, no affine gradients) with EIGHT
+// consecutive columns per lane: every 16-bit stream then moves 16 bytes per lane and instruction instead of 8 (8-byte accesses run at
+// 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md) -- four of this kernel's five streams are 16-bit.  cols % 8 == 0, cols <= 1024.
+__global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                      const int32_t* __restrict__ row_index, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const unsigned short* __restrict__ dres, unsigned short* __restrict__ dx,
+                                                      bf16_t* __restrict__ dxb, int lddx, int rows, int cols,
+                                                      const float* __restrict__ bscale, int rows_per_img) {
+    REID_T16_ENTER();
+    REID_F16_SATURATE();
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n8 = cols >> 3;
+    const size_t xrow = row_index ? (size_t)row_index[row] : (size_t)row;
+    const float* xr = x + xrow * ldx;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[2][8], g[2][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; g[i][e] = 0.f; }
+        if (c < n8) {
+            const f32x4 x0 = *(const f32x4*)(xr + c * 8), x1 = *(const f32x4*)(xr + c * 8 + 4);
+            const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+            const uint4 d = *(const uint4*)(dy + (size_t)row * lddy + c * 8);
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xv = e < 4 ? x0[e] : x1[e - 4], gm = e < 4 ? g0[e] : g1[e - 4];
+                const float dv = bf16_to_f32((bf16_t)((dw[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                xh[i][e] = (xv - mu) * rs;
+                g[i][e] = dv * gm;
+                s1 += g[i][e];
+                s2 = fmaf(g[i][e], xh[i][e], s2);
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / cols, m2 = wave_sum(s2) / cols;
+    const float bs = bscale ? bscale[xrow / rows_per_img] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + i * 64;
+        if (c < n8) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - m1 - xh[i][e] * m2);
+            if (dres) {
+                const uint4 r = *(const uint4*)(dres + xrow * lddx + c * 8);
+                const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += f16_to_f32((unsigned short)((rw[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+            }
+            *(uint4*)(dx + xrow * lddx + c * 8) = uint4{pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3]), pack_f16x2(o[4], o[5]), pack_f16x2(o[6], o[7])};
+            if (dxb)
+                *(uint4*)(dxb + xrow * lddx + c * 8) = uint4{pack_bf16x2(o[0] * bs, o[1] * bs), pack_bf16x2(o[2] * bs, o[3] * bs),
+                                                            pack_bf16x2(o[4] * bs, o[5] * bs), pack_bf16x2(o[6] * bs, o[7] * bs)};
+        }
+    }
+}
 }  // namespace
+
 
 extern "C" int reid_layernorm_fwd(const float* x, int32_t ldx, const int32_t* row_index, const float* gamma, const float* beta,
                                   void* y_bf16, float* y_f32, int32_t ldy, float* mean, float* rstd, int32_t rows,
@@ -449,6 +513,12 @@ extern "C" int reid_layernorm_bwd(const void* dy, int32_t dy_dtype, int32_t lddy
     hipStream_t s = (hipStream_t)stream;
     const bool aff = dgamma || dbeta;
     const bool hx = dx_dtype == REID_F16;
+    if (hx && dy_dtype == REID_BF16 && !aff && cols % 8 == 0 && cols <= 1024 && lddy % 8 == 0 && lddx % 8 == 0 && reid_knob(KNOB_LN_IMPL) != 1) {     // REID_LN_IMPL=1: the four-column form
+        hipLaunchKernelGGL(ln_bwd8_kernel, dim3((rows + 3) / 4), b, 0, s, (const bf16_t*)dy, lddy, x, ldx, row_index, gamma, mean, rstd,
+                           (const unsigned short*)dres, (unsigned short*)dx, (bf16_t*)dx_bf16, lddx, rows, cols, bf16_row_scale, rows_per_img);
+        REID_CHECK_LAUNCH("reid_layernorm_bwd");
+        return REID_OK;
+    }
 #define REID_LN_BWD3(B16, AFF, HX, VN)                                                                                         \
     hipLaunchKernelGGL((ln_bwd_kernel<B16, AFF, HX, VN>), g, b, 0, s, dy, lddy, x, ldx, row_index, gamma, mean, rstd, dres, dx, \
                        (bf16_t*)dx_bf16, lddx, dgamma, dbeta, rows, cols, bf16_row_scale, rows_per_img)
