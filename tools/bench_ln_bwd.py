@@ -1,4 +1,5 @@
-"""LayerNorm backward at the vision tower's size (50432 x 768), 16-bit cotangent in, residual-stream gradient in half / fp32: us per launch, TB/s."""
+"""(r04: the same eight-columns-per-lane form for add_ln_fwd measured SLOWER -- 90.9 vs 83.4 us: its two fp32 streams then move 32-byte
+strided pieces -- and was not kept.)  LayerNorm backward at the vision tower's size (50432 x 768), 16-bit cotangent in, residual-stream gradient in half / fp32: us per launch, TB/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,3 +20,17 @@ for dt, nb in ((torch.float16, 12), (torch.float32, 16)):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
     print(f'ln_bwd dx {str(dt):14s}: {us:6.1f} us  {rows * cols * nb / us / 1e6:5.2f} TB/s')
+
+# the fused residual add + LayerNorm forward at the same size (x fp32 in/out, branch output 16-bit in, h 16-bit out: 12 B per element)
+y = torch.randn(rows, cols, device='cuda', generator=g).to(torch.float16)
+xo = torch.empty_like(x); hb = torch.empty(rows, cols, device='cuda', dtype=_lib.t16()); beta = torch.zeros(cols, device='cuda')
+m2 = torch.empty(rows, device='cuda'); r2 = torch.empty(rows, device='cuda')
+def fwd(): ops.add_layernorm_fwd(x, y, xo, gam, beta, hb, m2, r2)
+for _ in range(5): fwd()
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): fwd()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 50 * 1e3
+print(f'add_ln_fwd                : {us:6.1f} us  {rows * cols * 12 / us / 1e6:5.2f} TB/s')
