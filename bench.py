@@ -77,7 +77,7 @@ PMC_FILE = 'r04_pmc_traffic.json'
 # kernels the roofline objects are about: the committed PMC summary must have been collected on a tree that dispatches kernels of
 # these names, or the traffic figure is refused (null + a note) instead of silently describing other code
 GEMM_KERNELS = ('mer_gemm_pps_kernel', 'mer_gemm_pp_kernel', 'mer_gemm_kernel<128, 128, 2, 2')
-LN_KERNELS = ('ln_bwd_kernel<true',)
+LN_KERNELS = ('ln_bwd8_kernel',)
 
 
 def pmc_traffic(prefixes, required=None):
@@ -613,12 +613,12 @@ def main():
         nb = sum(p[0] for p in ln_prof); ms = sum(p[1].elapsed_time(p[2]) for p in ln_prof)
         gbs = nb / (ms * 1e-3) / 1e9
         traffic, tnote = pmc_traffic(LN_KERNELS)
-        res['roofline_hbm'] = {'kernel': 'ln_bwd_kernel<true, false, true> (16-bit cotangent in, residual-stream gradient in IEEE half)', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+        res['roofline_hbm'] = {'kernel': 'ln_bwd8_kernel (16-bit cotangent in, residual-stream gradient in IEEE half, eight columns per lane)', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                'frac': gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_note': tnote, 'launches': len(ln_prof),
                                'avg_launch_us': ms * 1e3 / len(ln_prof), 'algorithmic_bytes_per_launch_avg': nb / len(ln_prof),
                                'note': 'event pairs around the launches inside the running step (the side stream shares the chip); since r04 the kernel '
-                                       'moves 12 B per element (residual-stream gradient in IEEE half) instead of 16: 90 us per launch alone against 106 '
-                                       '(rocprofv3), i.e. a shorter kernel at a lower fraction of the HBM peak'}
+                                       'moves 12 B per element (residual-stream gradient in IEEE half) instead of 16: 81-84 us per launch alone against 106 '
+                                       'for the r03 form, i.e. a shorter kernel at a lower fraction of the HBM peak'}
     res['flavors'] = {head: {'ms_per_step': elapsed / args.steps * 1e3, 'value': value, 'role': 'headline'}}
     if rank == 0 and not args.no_kernel_events:             # (profiled runs pass --no-kernel-events: their kernel trace is of the step only)
         # the head section alone at this rank's batch and at the global batches of configs 3 / 5: under DP every rank runs it on the GLOBAL
