@@ -1,5 +1,6 @@
 """(r04: the same eight-columns-per-lane form for add_ln_fwd measured SLOWER -- 90.9 vs 83.4 us: its two fp32 streams then move 32-byte
-strided pieces -- and was not kept.)  LayerNorm backward at the vision tower's size (50432 x 768), 16-bit cotangent in, residual-stream gradient in half / fp32: us per launch, TB/s."""
+strided pieces -- and was not kept; neither was a form that keeps the fp32 streams' mapping and regroups the two 16-bit streams through a wave-private LDS
+slice into 16-byte pieces: 84.4 vs 82.4 us.)  LayerNorm backward at the vision tower's size (50432 x 768), 16-bit cotangent in, residual-stream gradient in half / fp32: us per launch, TB/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
