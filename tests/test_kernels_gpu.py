@@ -755,6 +755,38 @@ def test_cosine_topk_query_resident_scan_equals_tiled_filter(ops, Nq, Ng, D, k, 
             assert abs(float(sm[qi, int(ref[qi, r])] - sm[qi, int(r_[0][qi, r])])) < 2e-7, (qi, r)
 
 
+def test_cosine_topk_query_resident_scan_on_a_shared_chip(ops):
+    """The scan's workgroups exchange their running maxima through memory and never wait for one another: when another stream holds
+    most of the chip (here: large GEMMs launched back to back on a second stream), some workgroups run long before the others, find no
+    complete bar, poll a bounded number of times and mark their queries for the exact pass.  Whatever the interleaving, the lists and
+    score bits must equal the tiled path's (and the call must return)."""
+    from prcv2025reid_amd import _lib
+    from prcv2025reid_amd.retrieval import GalleryIndex
+    Nq, Ng, D, k = 96, 150000, 512, 10
+    g = torch.Generator(device='cuda').manual_seed(5)
+    Q = torch.nn.functional.normalize(torch.randn(Nq, D, device='cuda', generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(Ng, D, device='cuda', generator=g), dim=1)
+    index = GalleryIndex(G, normalized=True)
+    try:
+        _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', 0))
+        want = index.topk(Q, k=k, normalized=True, stream=False)
+    finally:
+        _lib.check(_lib.lib().reid_set_knob(b'TOPK_SCAN', -1))
+    torch.cuda.synchronize()
+    A = torch.randn(16384, 4096, device='cuda', generator=g).to(T16()); B = torch.randn(4096, 4096, device='cuda', generator=g).to(T16())
+    C = torch.empty(16384, 4096, device='cuda', dtype=T16())
+    side = torch.cuda.Stream()
+    got = []
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4 + rep): ops.gemm(A, B, C)           # ~0.3 ms each: the chip is busy while the scan is dispatched
+        got.append(index.topk(Q, k=k, normalized=True, stream=False))
+    torch.cuda.synchronize()
+    for i_, s_ in got:
+        assert int((i_ < -1).sum()) == 0
+        assert torch.equal(i_, want[0]) and torch.equal(s_.view(torch.int32), want[1].view(torch.int32))
+
+
 def test_cosine_topk_query_resident_scan_without_a_bar(ops):
     """A query whose same-image id matches EVERY gallery row never gets a bar (none of its rows may count), and its whole 32-query wave
     then has none: the scan marks those queries for the exact pass instead of comparing against nothing.  Result = the tiled path's."""
