@@ -813,7 +813,9 @@ extern "C" int reid_mer_gemm(const reid_gemm_args* a, void* stream) {
                    "reid_mer_gemm: REID_F16 is supported for C only");
     // L2 group height of the tile order: 16 row tiles when the weight panel set is wide and K short (q|k|v, fc1: the whole
     // [N, K] weight no longer fits one XCD's L2 next to 8 activation tiles and was re-streamed per group; r01 sweep 4..64)
-    p.group_m = (p.K + p.K2 <= 1024 && p.N >= 1536) ? 16 : 8;
+    // r04, 256-row tiles, in-step A/B on one box (tools/exp_r04_ab.sh): 8 for every shape 30.73-30.79 ms per step, 16 for the wide short-K
+    // shapes (the r01 choice, made with 128-row tiles) 30.87-30.89, 4: 30.72-30.84, 16 everywhere 31.3, 32: 32.2
+    p.group_m = 8;
     if (reid_knob(KNOB_GEMM_GROUPM) > 0) p.group_m = reid_knob(KNOB_GEMM_GROUPM);
     p.perm_b = epilogue_wide16(p) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
